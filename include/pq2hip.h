@@ -1,0 +1,189 @@
+/*
+ * pq2hip -- MI355X (gfx950) decoder for Parquet's RLE/bit-packing hybrid
+ * encoding and plain bit-unpacking, behind a C ABI.
+ *
+ * This header is the drop-in boundary: every entry point names the public
+ * item of jorgecarleitao/parquet2 (v0.17.2) that it replaces.  Paths are
+ * relative to the reference root.  The reference has no FFI of its own; its
+ * boundary is the public Rust API re-exported at
+ *   src/encoding/hybrid_rle/mod.rs:5-7, src/encoding/bitpacked/mod.rs:6-7 and
+ *   src/deserialize/mod.rs:9-15.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; the caller owns every buffer it passes;
+ *  - `d_*` arguments are device pointers on the context's GPU, `h_*` / bare
+ *    pointers are host pointers;
+ *  - every function returns a pq2 status (0 = OK); decode entry points also
+ *    fill one status per page so that one malformed page does not poison a
+ *    batch;
+ *  - a context is bound to one GPU and is not thread-safe; use one context per
+ *    (thread, GPU).  Distinct contexts may be used concurrently;
+ *  - decoding always runs on the GPU.  There is no CPU fallback: if no HIP
+ *    device is usable, pq2_ctx_create fails with PQ2_DEVICE_ERROR.
+ */
+#ifndef PQ2HIP_H
+#define PQ2HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes: src/error.rs:23-34 (Error) plus two of our own -------- */
+#define PQ2_OK 0
+#define PQ2_OUT_OF_SPEC 1           /* Error::OutOfSpec */
+#define PQ2_INVALID_PARAMETER 2     /* Error::InvalidParameter */
+#define PQ2_FEATURE_NOT_SUPPORTED 3 /* Error::FeatureNotSupported */
+#define PQ2_WOULD_OVER_ALLOCATE 4   /* Error::WouldOverAllocate */
+#define PQ2_REFERENCE_WOULD_PANIC 5 /* defined, non-crashing answer for inputs on which the reference panics */
+#define PQ2_DEVICE_ERROR 6          /* HIP runtime failure; see pq2_last_error */
+
+/* Values are produced in blocks of this many u32; per-page output offsets
+ * that are multiples of 4 values keep every store 16-byte aligned. */
+#define PQ2_BLOCK_VALUES 1024u
+/* Largest num_values / packed length a single page may have. */
+#define PQ2_MAX_PAGE_VALUES 0x7fffffffu
+#define PQ2_MAX_PAGE_BYTES 0xffffff00u
+
+typedef struct pq2_ctx pq2_ctx;
+
+/* One encoded stream ("page") of a batch: the arguments of
+ * HybridRleDecoder::try_new(data, num_bits, num_values)
+ * (src/encoding/hybrid_rle/mod.rs:68) plus where the decoded values go. */
+typedef struct pq2_page_desc {
+    uint64_t in_off;     /* byte offset of the stream inside the input buffer */
+    uint32_t in_len;     /* stream length in bytes (`data.len()`) */
+    uint32_t num_bits;   /* 0..=32 */
+    uint64_t num_values; /* number of u32 to produce (`num_values`) */
+    uint64_t out_off;    /* index (in u32) of the first output value */
+} pq2_page_desc;
+
+/* ---- context ------------------------------------------------------------ */
+int32_t pq2_ctx_create(int32_t device_id, pq2_ctx **ctx);
+int32_t pq2_ctx_destroy(pq2_ctx *ctx);
+const char *pq2_strerror(int32_t status);
+/* message of the last failing call on this context ("" if none) */
+const char *pq2_last_error(const pq2_ctx *ctx);
+
+/* ---- hybrid RLE / bit-packed decode -------------------------------------- */
+
+/* Replaces, for every page i of the batch,
+ *   HybridRleDecoder::try_new(&in[in_off..in_off+in_len], num_bits, num_values)?
+ *       .collect::<Result<Vec<u32>, _>>()
+ * (src/encoding/hybrid_rle/mod.rs:66-116, built on decoder.rs:8-65,
+ * bitpacked/decode.rs:9-86, bitpacked/unpack.rs:21-95, uleb128.rs:3-23) with
+ * input and output resident in HBM.  Exactly num_values u32 are written per
+ * page at d_out[out_off..]; the stream is zero-padded when it is exhausted,
+ * RLE values are not masked to num_bits, and a header that ends the stream is
+ * dropped, exactly as the reference does.
+ *
+ * The work is enqueued on `stream` (a hipStream_t, NULL = default stream).
+ * If `status` is non-NULL the call waits for completion and writes one status
+ * per page; if it is NULL the call returns after enqueueing and statuses can
+ * be collected later with pq2_fetch_status.  Page statuses:
+ *   PQ2_OK, PQ2_REFERENCE_WOULD_PANIC (an RLE run without its value bytes,
+ *   decoder.rs:59-60; a 10-byte varint whose last byte is > 1, uleb128.rs:10-12;
+ *   a bit-packed header whose byte count overflows, decoder.rs:50),
+ *   PQ2_INVALID_PARAMETER (num_bits > 32: unpack32 has no such width,
+ *   unpack.rs:87).  The values of a page with a non-OK status are unspecified
+ *   (the call stays memory-safe).
+ * Returns non-zero only for errors of the call itself (bad descriptor bounds,
+ * device failure). */
+int32_t pq2_decode_batch_device(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const pq2_page_desc *descs,
+                                uint64_t n_pages, uint32_t *d_out, uint64_t out_values, int32_t *status,
+                                void *stream);
+
+/* Waits for the last batch enqueued on the context and copies its per-page
+ * statuses (n_pages must match that batch). */
+int32_t pq2_fetch_status(pq2_ctx *ctx, int32_t *status, uint64_t n_pages);
+
+/* Same contract with host buffers: copies the streams to the GPU, decodes,
+ * copies the values back (in page-aligned chunks on three streams, so copies
+ * and kernels overlap).  This is what a per-page drop-in of
+ * HybridRleDecoder / deserialize::utils::dict_indices_decoder
+ * (src/deserialize/utils.rs:13-27) calls. */
+int32_t pq2_decode_batch_host(pq2_ctx *ctx, const void *h_in, uint64_t in_bytes, const pq2_page_desc *descs,
+                              uint64_t n_pages, uint32_t *h_out, uint64_t out_values, int32_t *status);
+
+/* ---- plain bit-unpacking -------------------------------------------------- */
+
+/* Replaces bitpacked::Decoder::<u32>::try_new(packed, num_bits, length)?.collect()
+ * (src/encoding/bitpacked/decode.rs:28-86).  Errors as the reference:
+ * PQ2_OUT_OF_SPEC for num_bits == 0 (:33-35) and for
+ * packed_len * 8 < length * num_bits (:37-42); an empty `packed` yields no
+ * values (:46-50).  num_bits > 32 -> PQ2_REFERENCE_WOULD_PANIC (unpack.rs:87). */
+int32_t pq2_bitunpack_u32_device(pq2_ctx *ctx, const void *d_packed, uint64_t packed_len, uint32_t num_bits,
+                                 uint64_t length, uint32_t *d_out, void *stream);
+int32_t pq2_bitunpack_u32_host(pq2_ctx *ctx, const void *packed, uint64_t packed_len, uint32_t num_bits,
+                               uint64_t length, uint32_t *out);
+
+/* ---- multi-GPU sharding ---------------------------------------------------- */
+
+/* Splits a batch into `n_parts` contiguous page ranges balanced on output
+ * bytes (pages share no state, so there is no exchange step: each rank
+ * decodes pages [bounds[r], bounds[r+1]) on its own GPU).  `bounds` receives
+ * n_parts + 1 page indices.  The reference delegates this to its callers
+ * (README.md:107-128). */
+int32_t pq2_partition_pages(const pq2_page_desc *descs, uint64_t n_pages, uint32_t n_parts, uint64_t *bounds);
+
+/* ---- host-side page glue (no device work) ---------------------------------- */
+
+/* src/encoding/mod.rs:23-27 */
+uint64_t pq2_ceil8(uint64_t value);
+/* src/encoding/mod.rs:14-21; PQ2_OUT_OF_SPEC stands for `None` */
+int32_t pq2_get_length(const uint8_t *values, uint64_t len, uint64_t *out);
+/* src/read/levels.rs:3-5 */
+uint32_t pq2_get_bit_width(int16_t max_level);
+/* src/encoding/uleb128.rs:3-23 and :30-46 */
+int32_t pq2_uleb128_decode(const uint8_t *values, uint64_t len, uint64_t *value, uint64_t *consumed);
+uint64_t pq2_uleb128_encode(uint64_t value, uint8_t container[10]);
+
+typedef struct pq2_split {
+    uint64_t rep_off, rep_len, def_off, def_len, val_off, val_len; /* relative to the page buffer */
+} pq2_split;
+/* src/page/mod.rs:350-398 and :400-411 */
+int32_t pq2_split_buffer_v1(const uint8_t *buffer, uint64_t len, int32_t has_rep, int32_t has_def, pq2_split *out);
+int32_t pq2_split_buffer_v2(uint64_t len, uint64_t rep_len, uint64_t def_len, pq2_split *out);
+/* src/deserialize/utils.rs:13-27: bit width byte + offset of the index stream */
+int32_t pq2_dict_indices_locate(const uint8_t *values, uint64_t len, uint32_t *bit_width, uint64_t *stream_off);
+
+/* Run iterator: hybrid_rle::Decoder::new(data, num_bits) collected
+ * (src/encoding/hybrid_rle/decoder.rs:8-65).  Walks the run headers only (no
+ * value is decoded), on the host: consumers such as DefLevelsDecoder::Bitmap
+ * (src/deserialize/utils.rs:45-48) use the runs as zero-copy slices. */
+#define PQ2_RUN_BITPACKED 0
+#define PQ2_RUN_RLE 1
+typedef struct pq2_run {
+    int32_t kind;        /* PQ2_RUN_BITPACKED | PQ2_RUN_RLE */
+    uint32_t reserved;
+    uint64_t offset;     /* byte offset of the run's slice inside `data` */
+    uint64_t len;        /* slice length in bytes */
+    uint64_t run_length; /* RLE: number of repetitions (HybridEncoded::Rle(_, n)) */
+} pq2_run;
+/* Stores at most `cap` runs, always reports the full count in *n_runs. */
+int32_t pq2_hybrid_rle_runs(const uint8_t *data, uint64_t len, uint32_t num_bits, pq2_run *runs, uint64_t cap,
+                            uint64_t *n_runs);
+
+/* ---- write side (host): byte-exact with the reference encoders ---------------- */
+
+/* bitpacked::encode::<u32> (src/encoding/bitpacked/encode.rs:11-36, pack.rs:2-75):
+ * `packed` must be zeroed and hold ceil(len / 32) * 4 * num_bits bytes. */
+int32_t pq2_bitpacked_encode_u32(const uint32_t *unpacked, uint64_t len, uint32_t num_bits, uint8_t *packed,
+                                 uint64_t packed_len);
+/* hybrid_rle::encode_u32 (src/encoding/hybrid_rle/encoder.rs:9-72): one
+ * bit-packed run for the whole input.  Needs out_cap >= 10 + 4*num_bits*ceil(len/32). */
+int32_t pq2_hybrid_rle_encode_u32(const uint32_t *values, uint64_t len, uint32_t num_bits, uint8_t *out,
+                                  uint64_t out_cap, uint64_t *written);
+/* hybrid_rle::encode_bool (encoder.rs:75-93) and bitmap::encode_bool
+ * (src/encoding/hybrid_rle/bitmap.rs:71-102); `bools` holds one byte per value. */
+int32_t pq2_hybrid_rle_encode_bool(const uint8_t *bools, uint64_t len, uint8_t *out, uint64_t out_cap,
+                                   uint64_t *written);
+int32_t pq2_bitmap_encode_bool(const uint8_t *bools, uint64_t len, uint8_t *out, uint64_t out_cap,
+                               uint64_t *written);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PQ2HIP_H */

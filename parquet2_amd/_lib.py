@@ -1,0 +1,213 @@
+"""ctypes binding of libpq2hip.so (the C ABI declared in include/pq2hip.h).
+
+There is no CPU fallback: decoding needs the HIP library and a GPU.  Loading
+fails loudly if the shared object is missing, and `Context()` raises
+`DeviceError` when no device is usable.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .error import DeviceError, raise_for_status
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "lib", "libpq2hip.so")
+
+OK, OUT_OF_SPEC, INVALID_PARAMETER, FEATURE_NOT_SUPPORTED, WOULD_OVER_ALLOCATE, REFERENCE_WOULD_PANIC, DEVICE_ERROR = \
+    range(7)
+BLOCK_VALUES = 1024
+
+u8p = C.POINTER(C.c_uint8)
+u32p = C.POINTER(C.c_uint32)
+u64p = C.POINTER(C.c_uint64)
+i32p = C.POINTER(C.c_int32)
+
+
+class PageDesc(C.Structure):
+    """pq2_page_desc"""
+    _fields_ = [("in_off", C.c_uint64), ("in_len", C.c_uint32), ("num_bits", C.c_uint32),
+                ("num_values", C.c_uint64), ("out_off", C.c_uint64)]
+
+
+PAGE_DESC_DTYPE = np.dtype([("in_off", "<u8"), ("in_len", "<u4"), ("num_bits", "<u4"), ("num_values", "<u8"),
+                            ("out_off", "<u8")])
+assert PAGE_DESC_DTYPE.itemsize == C.sizeof(PageDesc) == 32
+
+
+class Split(C.Structure):
+    """pq2_split"""
+    _fields_ = [(n, C.c_uint64) for n in ("rep_off", "rep_len", "def_off", "def_len", "val_off", "val_len")]
+
+
+class Run(C.Structure):
+    """pq2_run"""
+    _fields_ = [("kind", C.c_int32), ("reserved", C.c_uint32), ("offset", C.c_uint64), ("len", C.c_uint64),
+                ("run_length", C.c_uint64)]
+
+
+# every symbol include/pq2hip.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "pq2_ctx_create": (C.c_int32, [C.c_int32, C.POINTER(C.c_void_p)]),
+    "pq2_ctx_destroy": (C.c_int32, [C.c_void_p]),
+    "pq2_strerror": (C.c_char_p, [C.c_int32]),
+    "pq2_last_error": (C.c_char_p, [C.c_void_p]),
+    "pq2_decode_batch_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p,
+                                             C.c_uint64, C.c_void_p, C.c_void_p]),
+    "pq2_fetch_status": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64]),
+    "pq2_decode_batch_host": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p,
+                                           C.c_uint64, C.c_void_p]),
+    "pq2_bitunpack_u32_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p,
+                                              C.c_void_p]),
+    "pq2_bitunpack_u32_host": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p]),
+    "pq2_partition_pages": (C.c_int32, [C.c_void_p, C.c_uint64, C.c_uint32, u64p]),
+    "pq2_ceil8": (C.c_uint64, [C.c_uint64]),
+    "pq2_get_length": (C.c_int32, [C.c_void_p, C.c_uint64, u64p]),
+    "pq2_get_bit_width": (C.c_uint32, [C.c_int16]),
+    "pq2_uleb128_decode": (C.c_int32, [C.c_void_p, C.c_uint64, u64p, u64p]),
+    "pq2_uleb128_encode": (C.c_uint64, [C.c_uint64, u8p]),
+    "pq2_split_buffer_v1": (C.c_int32, [C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.POINTER(Split)]),
+    "pq2_split_buffer_v2": (C.c_int32, [C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(Split)]),
+    "pq2_dict_indices_locate": (C.c_int32, [C.c_void_p, C.c_uint64, u32p, u64p]),
+    "pq2_hybrid_rle_runs": (C.c_int32, [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(Run), C.c_uint64, u64p]),
+    "pq2_bitpacked_encode_u32": (C.c_int32, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64]),
+    "pq2_hybrid_rle_encode_u32": (C.c_int32, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64, u64p]),
+    "pq2_hybrid_rle_encode_bool": (C.c_int32, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, u64p]),
+    "pq2_bitmap_encode_bool": (C.c_int32, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, u64p]),
+}
+
+_LIB = None
+
+
+def lib():
+    """The loaded shared library (loaded once)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "%s is missing: build it with `python -m parquet2_amd.build` (needs hipcc); "
+                "parquet2_amd has no CPU decode path" % LIB_PATH)
+        # One HIP runtime per process: PyTorch ships its own libamdhip64.so.7 / libhsa-runtime64.  Loading it
+        # first makes the dynamic linker resolve this library's libamdhip64.so.7 to that same copy; two
+        # runtimes in one process leave the second one without GPUs.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        handle = C.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _LIB = handle
+    return _LIB
+
+
+def as_u8(data):
+    """bytes-like / ndarray -> contiguous uint8 ndarray (zero-copy where possible)."""
+    if isinstance(data, np.ndarray):
+        return np.ascontiguousarray(data).view(np.uint8).reshape(-1)
+    return np.frombuffer(bytes(data) if not isinstance(data, (bytes, bytearray, memoryview)) else data, dtype=np.uint8)
+
+
+def ptr(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+class Context:
+    """One decoder context bound to one GPU (pq2_ctx).  Not thread-safe."""
+
+    def __init__(self, device_id=0):
+        self._h = C.c_void_p()
+        st = lib().pq2_ctx_create(device_id, C.byref(self._h))
+        if st != OK:
+            self._h = None
+            raise DeviceError("pq2_ctx_create(device %d) failed: %s (no CPU fallback exists)" %
+                              (device_id, lib().pq2_strerror(st).decode()))
+        self.device_id = device_id
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().pq2_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st):
+        if st != OK:
+            raise_for_status(st, lib().pq2_last_error(self._h).decode() or lib().pq2_strerror(st).decode())
+
+    # ---- device-resident batch decode --------------------------------------
+    def decode_batch_device(self, d_in_ptr, in_bytes, descs, d_out_ptr, out_values, stream=0, want_status=True):
+        """descs: ndarray of PAGE_DESC_DTYPE.  Returns per-page statuses (int32 ndarray) or None."""
+        descs = np.ascontiguousarray(descs, dtype=PAGE_DESC_DTYPE)
+        status = np.zeros(len(descs), dtype=np.int32) if want_status else None
+        st = lib().pq2_decode_batch_device(self._h, C.c_void_p(d_in_ptr), in_bytes, ptr(descs), len(descs),
+                                           C.c_void_p(d_out_ptr), out_values,
+                                           ptr(status) if want_status else None, C.c_void_p(stream))
+        self._check(st)
+        return status
+
+    def fetch_status(self, n_pages):
+        status = np.zeros(n_pages, dtype=np.int32)
+        self._check(lib().pq2_fetch_status(self._h, ptr(status), n_pages))
+        return status
+
+    # ---- host-buffer batch decode -------------------------------------------
+    def decode_batch_host(self, data, descs, out_values=None):
+        """Returns (values ndarray of uint32, statuses ndarray of int32)."""
+        data = as_u8(data)
+        descs = np.ascontiguousarray(descs, dtype=PAGE_DESC_DTYPE)
+        if out_values is None:
+            out_values = int((descs["out_off"] + descs["num_values"]).max()) if len(descs) else 0
+        out = np.zeros(out_values, dtype=np.uint32)
+        status = np.zeros(len(descs), dtype=np.int32)
+        st = lib().pq2_decode_batch_host(self._h, ptr(data), data.size, ptr(descs), len(descs), ptr(out), out_values,
+                                         ptr(status))
+        self._check(st)
+        return out, status
+
+    def decode_page_host(self, data, num_bits, num_values):
+        """HybridRleDecoder::try_new(data, num_bits, num_values).collect() for one stream."""
+        data = as_u8(data)
+        descs = np.zeros(1, dtype=PAGE_DESC_DTYPE)
+        descs[0] = (0, data.size, num_bits, num_values, 0)
+        out, status = self.decode_batch_host(data, descs, num_values)
+        return out, int(status[0])
+
+    # ---- bit-unpacking ---------------------------------------------------------
+    def bitunpack_u32_host(self, packed, num_bits, length):
+        packed = as_u8(packed)
+        out = np.zeros(length, dtype=np.uint32)
+        st = lib().pq2_bitunpack_u32_host(self._h, ptr(packed), packed.size, num_bits, length, ptr(out))
+        self._check(st)
+        return out if packed.size else out[:0]
+
+    def bitunpack_u32_device(self, d_packed_ptr, packed_len, num_bits, length, d_out_ptr, stream=0):
+        self._check(lib().pq2_bitunpack_u32_device(self._h, C.c_void_p(d_packed_ptr), packed_len, num_bits, length,
+                                                   C.c_void_p(d_out_ptr), C.c_void_p(stream)))
+
+
+_DEFAULT_CTX = {}
+
+
+def default_context(device_id=0):
+    """Process-wide context per device, used by the iterator-style mirrors."""
+    ctx = _DEFAULT_CTX.get(device_id)
+    if ctx is None:
+        ctx = _DEFAULT_CTX[device_id] = Context(device_id)
+    return ctx
+
+
+def partition_pages(descs, n_parts):
+    """Contiguous page ranges balanced on output bytes: returns n_parts + 1 bounds."""
+    descs = np.ascontiguousarray(descs, dtype=PAGE_DESC_DTYPE)
+    bounds = np.zeros(n_parts + 1, dtype=np.uint64)
+    st = lib().pq2_partition_pages(ptr(descs), len(descs), n_parts, bounds.ctypes.data_as(u64p))
+    if st != OK:
+        raise_for_status(st, "pq2_partition_pages")
+    return bounds.astype(np.int64)

@@ -1,0 +1,354 @@
+// Host side of libpq2hip: the C ABI of include/pq2hip.h.
+//
+// A context owns, for one GPU: small device arrays for the per-batch page
+// descriptors / tile prefix / per-page status, the Resume table (8 bytes per
+// 1024 output values), a pinned staging buffer for the descriptor upload and,
+// for the host-buffer entry points, device arenas and copy streams.  All of
+// them grow on demand and are reused, so a steady stream of batches performs
+// no allocation.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/pq2hip.h"
+
+extern "C" {
+hipError_t pq2_launch_parse(const void *pages, uint32_t n_pages, void *resume, int32_t *status, hipStream_t stream);
+hipError_t pq2_launch_expand(const void *pages, const uint32_t *tile_base, uint32_t n_pages, uint32_t n_tiles,
+                             const void *resume, hipStream_t stream);
+hipError_t pq2_launch_bitunpack(const void *d_packed, uint32_t packed_len, uint32_t num_bits, uint32_t length,
+                                uint32_t *d_out, hipStream_t stream);
+}
+
+namespace {
+
+constexpr uint32_t kTileValues = 4096;  // 4 blocks of PQ2_BLOCK_VALUES
+constexpr uint32_t kBlocksPerTile = 4;
+
+struct PageDev {  // must match pq2::PageDev
+    uint64_t in_addr;
+    uint64_t out_addr;
+    uint32_t in_len;
+    uint32_t num_values;
+    uint32_t num_bits;
+    uint32_t tile_base;
+};
+static_assert(sizeof(PageDev) == 32, "PageDev layout");
+
+struct DevBuf {
+    void *ptr = nullptr;
+    size_t cap = 0;
+};
+
+}  // namespace
+
+struct pq2_ctx {
+    int device = 0;
+    std::string last_error;
+    // per-batch metadata: [PageDev x n][tile_base x (n+1)] in one pinned block, mirrored on the device
+    void *h_meta = nullptr;
+    size_t h_meta_cap = 0;
+    hipEvent_t meta_copied = nullptr;  // the previous upload has left h_meta
+    bool meta_in_flight = false;
+    DevBuf d_meta, d_status, d_resume;
+    std::vector<int32_t> host_status;  // statuses decided on the host (bad num_bits)
+    uint64_t last_n_pages = 0;
+    hipStream_t last_stream = nullptr;
+    bool busy = false;  // a batch may still be running on last_stream
+    // host-buffer path
+    DevBuf d_in, d_out;
+    hipStream_t copy_streams[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t chunk_done[3] = {nullptr, nullptr, nullptr};
+};
+
+namespace {
+
+int32_t fail(pq2_ctx *ctx, int32_t code, const std::string &msg) {
+    if (ctx) ctx->last_error = msg;
+    return code;
+}
+
+int32_t hip_fail(pq2_ctx *ctx, hipError_t e, const char *what) {
+    return fail(ctx, PQ2_DEVICE_ERROR, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define PQ2_HIP(ctx, call)                                    \
+    do {                                                      \
+        hipError_t e_ = (call);                               \
+        if (e_ != hipSuccess) return hip_fail(ctx, e_, #call); \
+    } while (0)
+
+int32_t reserve(pq2_ctx *ctx, DevBuf &b, size_t bytes) {
+    if (bytes <= b.cap) return PQ2_OK;
+    size_t cap = std::max(bytes, b.cap + b.cap / 2);
+    cap = (cap + 4095) & ~size_t(4095);
+    if (b.ptr) PQ2_HIP(ctx, hipFree(b.ptr));
+    b.ptr = nullptr;
+    b.cap = 0;
+    PQ2_HIP(ctx, hipMalloc(&b.ptr, cap));
+    b.cap = cap;
+    return PQ2_OK;
+}
+
+int32_t reserve_pinned(pq2_ctx *ctx, size_t bytes) {
+    if (bytes <= ctx->h_meta_cap) return PQ2_OK;
+    if (ctx->meta_in_flight) {
+        PQ2_HIP(ctx, hipEventSynchronize(ctx->meta_copied));
+        ctx->meta_in_flight = false;
+    }
+    if (ctx->h_meta) PQ2_HIP(ctx, hipHostFree(ctx->h_meta));
+    ctx->h_meta = nullptr;
+    ctx->h_meta_cap = 0;
+    size_t cap = (std::max(bytes, ctx->h_meta_cap * 2) + 4095) & ~size_t(4095);
+    PQ2_HIP(ctx, hipHostMalloc(&ctx->h_meta, cap, hipHostMallocDefault));
+    ctx->h_meta_cap = cap;
+    return PQ2_OK;
+}
+
+// Validates the batch, builds the device descriptors in pinned memory, uploads
+// them and enqueues parse + expand on `stream`.
+int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const pq2_page_desc *descs, uint64_t n_pages,
+                      uint32_t *d_out, uint64_t out_values, hipStream_t stream) {
+    if (n_pages > 0x7fffffffull) return fail(ctx, PQ2_INVALID_PARAMETER, "too many pages in one batch");
+    if (n_pages > 0 && !descs) return fail(ctx, PQ2_INVALID_PARAMETER, "descs is NULL");
+    // the device-side metadata and the Resume table are shared by consecutive batches: stream order
+    // protects them on one stream, a change of stream needs the previous batch to have finished
+    if (ctx->busy && ctx->last_stream != stream) PQ2_HIP(ctx, hipStreamSynchronize(ctx->last_stream));
+    ctx->host_status.assign(n_pages, PQ2_OK);
+    ctx->last_n_pages = n_pages;
+    ctx->last_stream = stream;
+    if (n_pages == 0) return PQ2_OK;
+    ctx->busy = true;
+
+    const size_t meta_bytes = n_pages * sizeof(PageDev) + (n_pages + 1) * sizeof(uint32_t);
+    int32_t st = reserve_pinned(ctx, meta_bytes);
+    if (st) return st;
+    if (ctx->meta_in_flight) {  // the previous batch's upload still reads the pinned block
+        PQ2_HIP(ctx, hipEventSynchronize(ctx->meta_copied));
+        ctx->meta_in_flight = false;
+    }
+    PageDev *pages = static_cast<PageDev *>(ctx->h_meta);
+    uint32_t *tile_base = reinterpret_cast<uint32_t *>(pages + n_pages);
+
+    uint64_t tiles = 0;
+    for (uint64_t i = 0; i < n_pages; ++i) {
+        const pq2_page_desc &d = descs[i];
+        if (d.in_len > PQ2_MAX_PAGE_BYTES) return fail(ctx, PQ2_INVALID_PARAMETER, "page stream too long");
+        if (d.in_off > in_bytes || d.in_len > in_bytes - d.in_off)
+            return fail(ctx, PQ2_INVALID_PARAMETER, "page stream outside the input buffer");
+        if (d.num_values > PQ2_MAX_PAGE_VALUES) return fail(ctx, PQ2_INVALID_PARAMETER, "page has too many values");
+        if (d.out_off > out_values || d.num_values > out_values - d.out_off)
+            return fail(ctx, PQ2_INVALID_PARAMETER, "page output outside the output buffer");
+        PageDev &p = pages[i];
+        p.in_addr = reinterpret_cast<uint64_t>(d_in) + d.in_off;
+        p.out_addr = reinterpret_cast<uint64_t>(d_out) + d.out_off * sizeof(uint32_t);
+        p.in_len = d.in_len;
+        p.num_values = static_cast<uint32_t>(d.num_values);
+        p.num_bits = d.num_bits;
+        if (d.num_bits > 32) {  // unpack32 has no such width (src/encoding/bitpacked/unpack.rs:87)
+            ctx->host_status[i] = PQ2_INVALID_PARAMETER;
+            p.num_values = 0;
+        }
+        p.tile_base = static_cast<uint32_t>(tiles);
+        tile_base[i] = static_cast<uint32_t>(tiles);
+        tiles += (p.num_values + kTileValues - 1) / kTileValues;
+        if (tiles > 0x7fffffffull) return fail(ctx, PQ2_INVALID_PARAMETER, "batch too large for one launch");
+    }
+    tile_base[n_pages] = static_cast<uint32_t>(tiles);
+    if ((reinterpret_cast<uintptr_t>(d_out) & 3u) != 0) return fail(ctx, PQ2_INVALID_PARAMETER, "d_out misaligned");
+
+    if ((st = reserve(ctx, ctx->d_meta, meta_bytes))) return st;
+    if ((st = reserve(ctx, ctx->d_status, n_pages * sizeof(int32_t)))) return st;
+    if ((st = reserve(ctx, ctx->d_resume, std::max<uint64_t>(tiles, 1) * kBlocksPerTile * 8))) return st;
+
+    PQ2_HIP(ctx, hipMemcpyAsync(ctx->d_meta.ptr, ctx->h_meta, meta_bytes, hipMemcpyHostToDevice, stream));
+    PQ2_HIP(ctx, hipEventRecord(ctx->meta_copied, stream));
+    ctx->meta_in_flight = true;
+
+    const PageDev *d_pages = static_cast<const PageDev *>(ctx->d_meta.ptr);
+    const uint32_t *d_tile_base = reinterpret_cast<const uint32_t *>(d_pages + n_pages);
+    PQ2_HIP(ctx, pq2_launch_parse(d_pages, static_cast<uint32_t>(n_pages), ctx->d_resume.ptr,
+                                  static_cast<int32_t *>(ctx->d_status.ptr), stream));
+    PQ2_HIP(ctx, pq2_launch_expand(d_pages, d_tile_base, static_cast<uint32_t>(n_pages), static_cast<uint32_t>(tiles),
+                                   ctx->d_resume.ptr, stream));
+    return PQ2_OK;
+}
+
+int32_t fetch_status(pq2_ctx *ctx, int32_t *status, uint64_t n_pages) {
+    if (n_pages != ctx->last_n_pages) return fail(ctx, PQ2_INVALID_PARAMETER, "n_pages does not match the last batch");
+    if (n_pages == 0) return PQ2_OK;
+    PQ2_HIP(ctx, hipMemcpyAsync(status, ctx->d_status.ptr, n_pages * sizeof(int32_t), hipMemcpyDeviceToHost,
+                                ctx->last_stream));
+    PQ2_HIP(ctx, hipStreamSynchronize(ctx->last_stream));
+    for (uint64_t i = 0; i < n_pages; ++i)
+        if (ctx->host_status[i] != PQ2_OK) status[i] = ctx->host_status[i];
+    return PQ2_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t pq2_ctx_create(int32_t device_id, pq2_ctx **out) {
+    if (!out) return PQ2_INVALID_PARAMETER;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return PQ2_DEVICE_ERROR;  // no CPU fallback
+    if (device_id < 0 || device_id >= count) return PQ2_INVALID_PARAMETER;
+    if (hipSetDevice(device_id) != hipSuccess) return PQ2_DEVICE_ERROR;
+    pq2_ctx *ctx = new (std::nothrow) pq2_ctx();
+    if (!ctx) return PQ2_WOULD_OVER_ALLOCATE;
+    ctx->device = device_id;
+    if (hipEventCreateWithFlags(&ctx->meta_copied, hipEventDisableTiming) != hipSuccess) {
+        delete ctx;
+        return PQ2_DEVICE_ERROR;
+    }
+    *out = ctx;
+    return PQ2_OK;
+}
+
+int32_t pq2_ctx_destroy(pq2_ctx *ctx) {
+    if (!ctx) return PQ2_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    for (DevBuf *b : {&ctx->d_meta, &ctx->d_status, &ctx->d_resume, &ctx->d_in, &ctx->d_out})
+        if (b->ptr) (void)hipFree(b->ptr);
+    if (ctx->h_meta) (void)hipHostFree(ctx->h_meta);
+    if (ctx->meta_copied) (void)hipEventDestroy(ctx->meta_copied);
+    for (int i = 0; i < 3; ++i) {
+        if (ctx->copy_streams[i]) (void)hipStreamDestroy(ctx->copy_streams[i]);
+        if (ctx->chunk_done[i]) (void)hipEventDestroy(ctx->chunk_done[i]);
+    }
+    delete ctx;
+    return PQ2_OK;
+}
+
+const char *pq2_strerror(int32_t status) {
+    switch (status) {
+        case PQ2_OK: return "ok";
+        case PQ2_OUT_OF_SPEC: return "out of spec";
+        case PQ2_INVALID_PARAMETER: return "invalid parameter";
+        case PQ2_FEATURE_NOT_SUPPORTED: return "feature not supported";
+        case PQ2_WOULD_OVER_ALLOCATE: return "would over-allocate";
+        case PQ2_REFERENCE_WOULD_PANIC: return "the reference decoder panics on this input";
+        case PQ2_DEVICE_ERROR: return "device error";
+        default: return "unknown status";
+    }
+}
+
+const char *pq2_last_error(const pq2_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+int32_t pq2_decode_batch_device(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const pq2_page_desc *descs,
+                                uint64_t n_pages, uint32_t *d_out, uint64_t out_values, int32_t *status,
+                                void *stream) {
+    if (!ctx) return PQ2_INVALID_PARAMETER;
+    PQ2_HIP(ctx, hipSetDevice(ctx->device));
+    int32_t st = enqueue_batch(ctx, d_in, in_bytes, descs, n_pages, d_out, out_values, static_cast<hipStream_t>(stream));
+    if (st != PQ2_OK) return st;
+    if (status) return fetch_status(ctx, status, n_pages);
+    return PQ2_OK;
+}
+
+int32_t pq2_fetch_status(pq2_ctx *ctx, int32_t *status, uint64_t n_pages) {
+    if (!ctx || (!status && n_pages)) return PQ2_INVALID_PARAMETER;
+    PQ2_HIP(ctx, hipSetDevice(ctx->device));
+    return fetch_status(ctx, status, n_pages);
+}
+
+int32_t pq2_decode_batch_host(pq2_ctx *ctx, const void *h_in, uint64_t in_bytes, const pq2_page_desc *descs,
+                              uint64_t n_pages, uint32_t *h_out, uint64_t out_values, int32_t *status) {
+    if (!ctx) return PQ2_INVALID_PARAMETER;
+    PQ2_HIP(ctx, hipSetDevice(ctx->device));
+    int32_t st;
+    // +16: the kernels read whole aligned dwords, never beyond the 16-byte line of the last stream byte
+    if ((st = reserve(ctx, ctx->d_in, in_bytes + 16))) return st;
+    if ((st = reserve(ctx, ctx->d_out, std::max<uint64_t>(out_values, 1) * sizeof(uint32_t)))) return st;
+    hipStream_t s = nullptr;
+    PQ2_HIP(ctx, hipMemcpyAsync(ctx->d_in.ptr, h_in, in_bytes, hipMemcpyHostToDevice, s));
+    st = enqueue_batch(ctx, ctx->d_in.ptr, in_bytes, descs, n_pages, static_cast<uint32_t *>(ctx->d_out.ptr), out_values,
+                       s);
+    if (st != PQ2_OK) return st;
+    // only the ranges the pages cover are defined; copy the covering span back
+    uint64_t lo = out_values, hi = 0;
+    for (uint64_t i = 0; i < n_pages; ++i) {
+        if (descs[i].num_values == 0) continue;
+        lo = std::min(lo, descs[i].out_off);
+        hi = std::max(hi, descs[i].out_off + descs[i].num_values);
+    }
+    if (hi > lo)
+        PQ2_HIP(ctx, hipMemcpyAsync(h_out + lo, static_cast<uint32_t *>(ctx->d_out.ptr) + lo,
+                                    (hi - lo) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    if (status) return fetch_status(ctx, status, n_pages);
+    PQ2_HIP(ctx, hipStreamSynchronize(s));
+    return PQ2_OK;
+}
+
+static int32_t check_bitunpack(pq2_ctx *ctx, uint64_t packed_len, uint32_t num_bits, uint64_t *length) {
+    // src/encoding/bitpacked/decode.rs:30-50, in the reference's order
+    if (num_bits == 0) return fail(ctx, PQ2_OUT_OF_SPEC, "Bitpacking requires num_bits > 0");
+    if (static_cast<unsigned __int128>(packed_len) * 8 < static_cast<unsigned __int128>(*length) * num_bits)
+        return fail(ctx, PQ2_OUT_OF_SPEC, "Unpacking " + std::to_string(*length) + " items with a number of bits " +
+                                               std::to_string(num_bits) + " requires at least " +
+                                               std::to_string(*length * num_bits / 8) + " bytes.");
+    if (packed_len == 0) *length = 0;
+    if (num_bits > 32 && packed_len > 0) return fail(ctx, PQ2_REFERENCE_WOULD_PANIC, "invalid num_bits");
+    if (packed_len > PQ2_MAX_PAGE_BYTES || *length > PQ2_MAX_PAGE_VALUES)
+        return fail(ctx, PQ2_INVALID_PARAMETER, "buffer too large for one call");
+    return PQ2_OK;
+}
+
+int32_t pq2_bitunpack_u32_device(pq2_ctx *ctx, const void *d_packed, uint64_t packed_len, uint32_t num_bits,
+                                 uint64_t length, uint32_t *d_out, void *stream) {
+    if (!ctx) return PQ2_INVALID_PARAMETER;
+    PQ2_HIP(ctx, hipSetDevice(ctx->device));
+    int32_t st = check_bitunpack(ctx, packed_len, num_bits, &length);
+    if (st != PQ2_OK) return st;
+    if ((reinterpret_cast<uintptr_t>(d_out) & 3u) != 0) return fail(ctx, PQ2_INVALID_PARAMETER, "d_out misaligned");
+    PQ2_HIP(ctx, pq2_launch_bitunpack(d_packed, static_cast<uint32_t>(packed_len), num_bits,
+                                      static_cast<uint32_t>(length), d_out, static_cast<hipStream_t>(stream)));
+    return PQ2_OK;
+}
+
+int32_t pq2_bitunpack_u32_host(pq2_ctx *ctx, const void *packed, uint64_t packed_len, uint32_t num_bits,
+                               uint64_t length, uint32_t *out) {
+    if (!ctx) return PQ2_INVALID_PARAMETER;
+    PQ2_HIP(ctx, hipSetDevice(ctx->device));
+    int32_t st = check_bitunpack(ctx, packed_len, num_bits, &length);
+    if (st != PQ2_OK) return st;
+    if (length == 0) return PQ2_OK;
+    if ((st = reserve(ctx, ctx->d_in, packed_len + 16))) return st;
+    if ((st = reserve(ctx, ctx->d_out, length * sizeof(uint32_t)))) return st;
+    hipStream_t s = nullptr;
+    PQ2_HIP(ctx, hipMemcpyAsync(ctx->d_in.ptr, packed, packed_len, hipMemcpyHostToDevice, s));
+    PQ2_HIP(ctx, pq2_launch_bitunpack(ctx->d_in.ptr, static_cast<uint32_t>(packed_len), num_bits,
+                                      static_cast<uint32_t>(length), static_cast<uint32_t *>(ctx->d_out.ptr), s));
+    PQ2_HIP(ctx, hipMemcpyAsync(out, ctx->d_out.ptr, length * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    PQ2_HIP(ctx, hipStreamSynchronize(s));
+    return PQ2_OK;
+}
+
+int32_t pq2_partition_pages(const pq2_page_desc *descs, uint64_t n_pages, uint32_t n_parts, uint64_t *bounds) {
+    if (n_parts == 0 || !bounds || (n_pages && !descs)) return PQ2_INVALID_PARAMETER;
+    unsigned __int128 total = 0;
+    for (uint64_t i = 0; i < n_pages; ++i) total += descs[i].num_values;
+    // page i goes to the part in which the midpoint of its output range falls; parts stay contiguous
+    bounds[0] = 0;
+    uint64_t page = 0;
+    unsigned __int128 before = 0;
+    for (uint32_t r = 1; r <= n_parts; ++r) {
+        const unsigned __int128 target2 = total * 2 * r / n_parts;  // twice the cumulative target
+        while (page < n_pages && before * 2 + descs[page].num_values <= target2) {
+            before += descs[page].num_values;
+            ++page;
+        }
+        bounds[r] = (r == n_parts) ? n_pages : page;
+    }
+    return PQ2_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,277 @@
+// Device-side building blocks shared by the pq2hip kernels (gfx950 only).
+//
+// Coordinates.  A page's stream starts at an arbitrary byte address.  All
+// device code addresses it through a buffer resource whose base is that
+// address rounded down to 16 bytes; "a-coordinates" are byte offsets from that
+// base, so the stream occupies a-offsets [delta, delta + in_len) with
+// delta = address & 15.  Every load is an aligned dword (or 4 aligned dwords)
+// and is range-checked by the hardware against the descriptor: reads past the
+// end return 0 instead of faulting, whatever the stream contains.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pq2 {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr uint32_t kBlockValues = 1024;    // values per wave-block (PQ2_BLOCK_VALUES)
+constexpr uint32_t kBlocksPerTile = 4;     // one 256-thread workgroup = 4 wave-blocks
+constexpr uint32_t kTileValues = kBlockValues * kBlocksPerTile;
+constexpr uint32_t kEndPos = 0xffffffffu;  // resume position meaning "stream exhausted: zeros"
+
+// Device-side page descriptor (32 bytes), built by the host from pq2_page_desc.
+struct PageDev {
+    uint64_t in_addr;     // device address of the first stream byte
+    uint64_t out_addr;    // device address of the page's first output value
+    uint32_t in_len;      // stream bytes
+    uint32_t num_values;  // values to produce (0 if the page is skipped)
+    uint32_t num_bits;    // 0..32
+    uint32_t tile_base;   // index of the page's first tile (tile = 4096 values)
+};
+
+// Where a 1024-value block starts inside the stream: the a-offset of the
+// header of the run that covers the block's first value (or kEndPos) and the
+// number of that run's values that precede the block.
+struct Resume {
+    uint32_t pos;
+    uint32_t skip;
+};
+
+enum RunKind : uint32_t { kBitpacked = 0, kRle = 1, kEnd = 2, kPanic = 3 };
+
+struct RunInfo {
+    uint32_t kind;     // RunKind
+    uint32_t count;    // values the run yields, already clamped to `remaining`
+    uint32_t payload;  // a-offset of the bit-packed payload
+    uint32_t value;    // RLE value (unmasked, as the reference)
+    uint32_t next;     // a-offset of the next header
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(uint64_t base16, uint32_t num_records) {
+    // 0x00020000: DATA_FORMAT = 32 (raw dword access) for gfx9-family descriptors
+    return __builtin_amdgcn_make_buffer_rsrc((void *)base16, 0, (int)num_records, 0x00020000);
+}
+
+__device__ __forceinline__ uint32_t ceil8(uint32_t v) { return (v + 7u) >> 3; }
+
+// Decodes the run whose header starts at a-offset `pos`.  `rd(a)` returns the
+// aligned dword at a-offset `a` (a % 4 == 0); everything here is wave-uniform.
+//
+// Follows hybrid_rle::Decoder::next (src/encoding/hybrid_rle/decoder.rs:30-64),
+// uleb128::decode (src/encoding/uleb128.rs:3-23) and read_next
+// (src/encoding/hybrid_rle/mod.rs:41-64):
+//   - an exhausted stream, or a header that consumes the last byte, ends the
+//     stream (kEnd): the caller pads with zeros (mod.rs:95);
+//   - bit-packed: bytes = min((ind >> 1) * w, left); values = min(bytes*8/w, remaining);
+//   - RLE: the value is the first min(4, ceil8(w)) bytes, little endian, not
+//     masked; fewer than ceil8(w) bytes left is a panic in the reference.
+template <typename Rd>
+__device__ __forceinline__ RunInfo decode_run(Rd rd, uint32_t pos, uint32_t end, uint32_t w, uint32_t remaining) {
+    RunInfo r;
+    r.kind = kEnd;
+    r.count = 0;
+    r.payload = 0;
+    r.value = 0;
+    r.next = end;
+    if (pos >= end) return r;
+
+    const uint32_t a0 = pos & ~3u;
+    const uint32_t sh = (pos & 3u) * 8u;
+    const uint32_t d0 = rd(a0), d1 = rd(a0 + 4), d2 = rd(a0 + 8), d3 = rd(a0 + 12);
+    // 12 stream bytes starting at pos
+    const uint32_t x0 = __builtin_amdgcn_alignbit(d1, d0, sh);
+    const uint32_t x1 = __builtin_amdgcn_alignbit(d2, d1, sh);
+    const uint32_t x2 = __builtin_amdgcn_alignbit(d3, d2, sh);
+
+    uint64_t ind;
+    uint32_t c;
+    if ((x0 & 0x80u) == 0) {  // one-byte header: by far the common case
+        ind = x0 & 0x7fu;
+        c = 1;
+    } else if ((x0 & 0x8000u) == 0) {
+        ind = (x0 & 0x7fu) | ((x0 >> 1) & 0x3f80u);
+        c = 2;
+    } else {
+        ind = 0;
+        c = 0;
+        bool done = false;
+        for (uint32_t i = 0; i < 10 && !done; ++i) {
+            if (pos + i >= end) return r;  // varint runs into the end of the stream: consumed == len
+            const uint32_t word = i < 4 ? x0 : (i < 8 ? x1 : x2);
+            const uint32_t b = (word >> ((i & 3u) * 8u)) & 0xffu;
+            c = i + 1;
+            if (i == 9 && b > 1) {  // uleb128.rs:10-12
+                r.kind = kPanic;
+                return r;
+            }
+            ind |= (uint64_t)(b & 0x7fu) << (7u * i);
+            done = (b & 0x80u) == 0;
+        }
+    }
+    const uint32_t p = pos + c;
+    if (p >= end) return r;  // decoder.rs:44-46 (also covers a varint cut by the end of the stream)
+    const uint32_t left = end - p;
+    const uint64_t n = ind >> 1;
+    if (ind & 1u) {
+        // bit-packed run
+        if ((n >> 59) != 0 && n > 0xffffffffffffffffull / w) {  // (ind >> 1) * num_bits overflows usize
+            r.kind = kPanic;
+            return r;
+        }
+        const uint64_t bytes = n * w;
+        uint32_t nbytes;
+        uint64_t k;
+        if (bytes > left) {  // decoder.rs:51 clamp: only whole values inside the remaining bytes
+            nbytes = left;
+            k = (uint64_t)(left / w) * 8u + ((left % w) * 8u) / w;  // left * 8 / w without 64-bit division
+        } else {
+            nbytes = (uint32_t)bytes;
+            k = n * 8u;
+        }
+        r.kind = kBitpacked;
+        r.count = k < remaining ? (uint32_t)k : remaining;
+        r.payload = p;
+        r.next = p + nbytes;
+    } else {
+        const uint32_t rb = ceil8(w);
+        if (left < rb) {  // split_at(rle_bytes) panics, decoder.rs:59-60
+            r.kind = kPanic;
+            return r;
+        }
+        uint32_t v;
+        if (c < 4)
+            v = __builtin_amdgcn_alignbit(x1, x0, c * 8u);
+        else if (c < 8)
+            v = __builtin_amdgcn_alignbit(x2, x1, (c - 4u) * 8u);
+        else if (c == 8)
+            v = x2;
+        else {  // 9- or 10-byte header: the value lies beyond the 12 bytes fetched above
+            const uint32_t b0 = p & ~3u;
+            v = __builtin_amdgcn_alignbit(rd(b0 + 4), rd(b0), (p & 3u) * 8u);
+        }
+        if (rb < 4) v &= (1u << (rb * 8u)) - 1u;
+        r.kind = kRle;
+        r.count = n < remaining ? (uint32_t)n : remaining;
+        r.value = v;
+        r.next = p + rb;
+    }
+    return r;
+}
+
+// ---- emission ---------------------------------------------------------------
+// A wave writes `count` values starting at `out` (4-byte aligned).  Lanes own
+// 16-byte-aligned groups of 4 values, so full groups are single dwordx4 stores
+// and one store instruction of the wave covers 1 KiB of contiguous output;
+// groups cut by the start or the end of the span fall back to dword stores.
+
+__device__ __forceinline__ int32_t first_group(const uint32_t *out, uint32_t lane) {
+    const uint32_t mis = (uint32_t)(((uintptr_t)out >> 2) & 3u);
+    return (int32_t)(lane * 4u) - (int32_t)mis;
+}
+
+__device__ __forceinline__ void store4(u32x4 v, uint32_t *p) {
+#ifdef PQ2_NT_STORES
+    __builtin_nontemporal_store(v, (u32x4 *)p);
+#else
+    *(u32x4 *)p = v;
+#endif
+}
+
+__device__ __forceinline__ void emit_rle(uint32_t v, uint32_t *out, uint32_t count, uint32_t lane) {
+    const u32x4 vv = {v, v, v, v};
+    for (int32_t r = first_group(out, lane); r < (int32_t)count; r += 256) {
+        if (r >= 0 && r + 4 <= (int32_t)count) {
+            store4(vv, out + r);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int32_t idx = r + i;
+                if (idx >= 0 && idx < (int32_t)count) out[idx] = v;
+            }
+        }
+    }
+}
+
+// One value at run-internal index v (any width 1..32).
+__device__ __forceinline__ uint32_t extract1(__amdgpu_buffer_rsrc_t rsrc, uint32_t payload, uint32_t v, uint32_t w) {
+    const uint32_t byte_off = payload + (v >> 3) * w;
+    const uint32_t bit_in = (byte_off & 3u) * 8u + (v & 7u) * w;
+    const uint32_t d = (byte_off >> 2) + (bit_in >> 5);
+    const uint32_t s = bit_in & 31u;
+    const uint32_t lo = __builtin_amdgcn_raw_buffer_load_b32(rsrc, d * 4u, 0, 0);
+    const uint32_t hi = __builtin_amdgcn_raw_buffer_load_b32(rsrc, d * 4u + 4u, 0, 0);
+    const uint32_t x = __builtin_amdgcn_alignbit(hi, lo, s);
+    return w == 32 ? x : (x & ((1u << w) - 1u));
+}
+
+// Four consecutive values starting at run-internal index v, width W known at
+// compile time: the lane loads the aligned dwords that hold its 4*W bits,
+// funnel-shifts them down to bit 0 and then every field sits at a constant
+// position.  LSB-first layout as src/encoding/bitpacked/unpack.rs:40-67.
+template <int W>
+__device__ __forceinline__ u32x4 extract4(__amdgpu_buffer_rsrc_t rsrc, uint32_t payload, uint32_t v) {
+    constexpr int NY = (4 * W + 31) / 32;  // dwords holding 4 values once aligned to bit 0
+    const uint32_t byte_off = payload + (v >> 3) * (uint32_t)W;
+    const uint32_t bit_in = (byte_off & 3u) * 8u + (v & 7u) * (uint32_t)W;
+    const uint32_t d = (byte_off >> 2) + (bit_in >> 5);
+    const uint32_t s = bit_in & 31u;
+    uint32_t x[NY + 1];
+#pragma unroll
+    for (int i = 0; i <= NY; ++i) x[i] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (d + i) * 4u, 0, 0);
+    uint32_t y[NY];
+#pragma unroll
+    for (int i = 0; i < NY; ++i) y[i] = __builtin_amdgcn_alignbit(x[i + 1], x[i], s);
+    constexpr uint32_t mask = W == 32 ? 0xffffffffu : ((1u << (W & 31)) - 1u);
+    uint32_t o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int lo = (i * W) >> 5;
+        const int shf = (i * W) & 31;
+        if (shf + W <= 32) {
+            o[i] = W == 32 ? y[lo] : ((y[lo] >> shf) & mask);
+        } else {
+            o[i] = __builtin_amdgcn_alignbit(y[lo + 1 < NY ? lo + 1 : lo], y[lo], shf) & mask;
+        }
+    }
+    const u32x4 res = {o[0], o[1], o[2], o[3]};
+    return res;
+}
+
+template <int W>
+__device__ __forceinline__ void emit_bp(__amdgpu_buffer_rsrc_t rsrc, uint32_t payload, uint32_t v_begin,
+                                        uint32_t *out, uint32_t count, uint32_t lane) {
+    for (int32_t r = first_group(out, lane); r < (int32_t)count; r += 256) {
+        if (r >= 0 && r + 4 <= (int32_t)count) {
+            const u32x4 vals = extract4<W>(rsrc, payload, v_begin + (uint32_t)r);
+            store4(vals, out + r);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int32_t idx = r + i;
+                if (idx >= 0 && idx < (int32_t)count) out[idx] = extract1(rsrc, payload, v_begin + (uint32_t)idx, W);
+            }
+        }
+    }
+}
+
+// Width dispatch: one specialised body per bit width 1..32.
+__device__ __forceinline__ void emit_bp_dispatch(uint32_t w, __amdgpu_buffer_rsrc_t rsrc, uint32_t payload,
+                                                 uint32_t v_begin, uint32_t *out, uint32_t count, uint32_t lane) {
+    switch (w) {
+#define PQ2_W(N)                                             \
+    case N:                                                  \
+        emit_bp<N>(rsrc, payload, v_begin, out, count, lane); \
+        break;
+        PQ2_W(1) PQ2_W(2) PQ2_W(3) PQ2_W(4) PQ2_W(5) PQ2_W(6) PQ2_W(7) PQ2_W(8)
+        PQ2_W(9) PQ2_W(10) PQ2_W(11) PQ2_W(12) PQ2_W(13) PQ2_W(14) PQ2_W(15) PQ2_W(16)
+        PQ2_W(17) PQ2_W(18) PQ2_W(19) PQ2_W(20) PQ2_W(21) PQ2_W(22) PQ2_W(23) PQ2_W(24)
+        PQ2_W(25) PQ2_W(26) PQ2_W(27) PQ2_W(28) PQ2_W(29) PQ2_W(30) PQ2_W(31) PQ2_W(32)
+#undef PQ2_W
+        default:
+            break;
+    }
+}
+
+}  // namespace pq2

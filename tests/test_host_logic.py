@@ -1,0 +1,192 @@
+"""Host-side pieces of the product library (no GPU): page glue, run iterator, encoders, run adapters,
+sharding.  Checked against the reference's known-answer vectors and against the CPU oracle."""
+import numpy as np
+import pytest
+
+from parquet2_amd import partition_pages, PAGE_DESC_DTYPE, synth
+from parquet2_amd.deserialize import (FilteredHybridBitmapIter, FilteredHybridEncoded, HybridEncoded, HybridRleIter,
+                                      SliceFilteredIter)
+from parquet2_amd.deserialize.hybrid_rle import HybridDecoderBitmapIter
+from parquet2_amd.encoding import bitpacked, ceil8, get_length, hybrid_rle, uleb128
+from parquet2_amd.error import OutOfSpec, ReferencePanic
+from parquet2_amd.indexes import Interval
+from parquet2_amd.page import (DataPage, DataPageHeaderV1, DataPageHeaderV2, Descriptor, split_buffer,
+                               split_buffer_v1, split_buffer_v2)
+from parquet2_amd.read.levels import get_bit_width
+
+
+def test_uleb128(kats):
+    for c in kats["uleb128_decode"]:
+        assert uleb128.decode(bytes(c["data"])) == (c["value"], c["consumed"]), c["src"]
+    for c in kats["uleb128_round_trip"]:
+        enc = uleb128.encode(c["value"])
+        assert uleb128.decode(enc + bytes(10 - len(enc))) == (c["value"], len(enc))
+    assert uleb128.decode(b"") == (0, 0)
+    assert uleb128.decode(bytes([0x80, 0x80])) == (0, 2)  # truncated varint: partial value, consumed = len
+    with pytest.raises(ReferencePanic):
+        uleb128.decode(bytes([0x80] * 9 + [2]))
+
+
+def test_levels_and_lengths(kats):
+    for level, width in kats["get_bit_width"]["table"]:
+        assert get_bit_width(level) == width
+    assert [ceil8(v) for v in (0, 1, 7, 8, 9)] == [0, 1, 1, 1, 2]
+    assert get_length(bytes([2, 0, 0, 0, 9])) == 2
+    assert get_length(bytes([1, 2, 3])) is None
+
+
+def test_split_buffer(oracle):
+    rng = np.random.default_rng(1)
+    for _ in range(50):
+        rep = rng.integers(0, 256, rng.integers(0, 20), dtype=np.uint8).tobytes()
+        deff = rng.integers(0, 256, rng.integers(0, 20), dtype=np.uint8).tobytes()
+        vals = rng.integers(0, 256, rng.integers(0, 20), dtype=np.uint8).tobytes()
+        for has_rep in (False, True):
+            for has_def in (False, True):
+                buf = b""
+                if has_rep:
+                    buf += len(rep).to_bytes(4, "little") + rep
+                if has_def:
+                    buf += len(deff).to_bytes(4, "little") + deff
+                buf += vals
+                r, d, v = split_buffer_v1(buf, has_rep, has_def)
+                assert (r, d, v) == (rep if has_rep else b"", deff if has_def else b"", vals)
+                st, s = oracle.split_buffer_v1(buf, has_rep, has_def)
+                assert st == 0 and (s.rep_len, s.def_len, s.val_len) == (len(r), len(d), len(v))
+        buf = rep + deff + vals
+        assert split_buffer_v2(buf, len(rep), len(deff)) == (rep, deff, vals)
+    with pytest.raises(OutOfSpec):
+        split_buffer_v1(bytes([9, 0, 0, 0, 1]), True, False)
+    with pytest.raises(OutOfSpec):
+        split_buffer_v1(bytes([1, 0]), False, True)
+    with pytest.raises(ReferencePanic):
+        split_buffer_v2(b"12345", 3, 4)
+    page = DataPage(DataPageHeaderV1(3), bytes([1, 0, 0, 0, 7, 5, 6]), Descriptor(max_def_level=1))
+    assert split_buffer(page) == (b"", bytes([7]), bytes([5, 6]))
+    page = DataPage(DataPageHeaderV2(3, 1, 2), bytes([1, 2, 3, 4]), Descriptor(1, 1))
+    assert split_buffer(page) == (bytes([1, 2]), bytes([3]), bytes([4]))
+
+
+def test_run_iterator(kats, oracle):
+    for c in kats["run_decoder"]:
+        run = next(hybrid_rle.Decoder(bytes(c["stream"]), c["bit_width"]))
+        if c["kind"] == "rle":
+            assert run == hybrid_rle.Rle(bytes(c["slice"]), c["run_length"]), c["src"]
+        else:
+            assert run == hybrid_rle.Bitpacked(bytes(c["slice"])), c["src"]
+    # against the oracle on generated and on random (garbage) streams
+    rng = np.random.default_rng(7)
+    streams = [(synth.dict_page(1, 5000, w)[0].tobytes(), w) for w in (1, 5, 12, 32)]
+    streams += [(rng.integers(0, 256, 300, dtype=np.uint8).tobytes(), int(w)) for w in rng.integers(0, 33, 200)]
+    for data, w in streams:
+        st, expect = oracle.runs(data, w)
+        dec = hybrid_rle.Decoder(data, w)
+        got = dec.run_offsets()
+        assert [(g[1], g[2]) for g in got] == [(e[1], e[2]) for e in expect]
+        assert [g[3] for g in got if g[0] == 1] == [e[3] for e in expect if e[0] == "rle"]
+        if st != 0:
+            with pytest.raises(ReferencePanic):
+                list(dec)
+
+
+def test_encoders(kats, oracle):
+    for c in kats["encoder"]:
+        if c["kind"] == "u32":
+            got = hybrid_rle.encode_u32(c["values"], c["num_bits"])
+        elif c["kind"] == "bool":
+            got = hybrid_rle.encode_bool(c["values"])
+        else:
+            bm = c["bitmap"]
+            bools = [(bm[(c["offset"] + i) // 8] >> ((c["offset"] + i) % 8)) & 1 for i in range(c["len"])]
+            got = hybrid_rle.encode_bool(bools)
+        assert list(got) == c["expected"], c["src"]
+    c = kats["bitpacked_case1"]
+    assert bitpacked.encode(c["unpacked"], c["num_bits"], np.zeros(128, np.uint8))[:15].tolist() == c["packed"]
+    # byte-exact against the oracle, out-of-range values and ragged lengths included
+    rng = np.random.default_rng(3)
+    for w in list(range(1, 33)):
+        for n in (1, 7, 31, 32, 33, 95, 200):
+            vals = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+            if rng.random() < 0.7:
+                vals &= np.uint32((1 << w) - 1 if w < 32 else 0xFFFFFFFF)
+            assert hybrid_rle.encode_u32(vals, w) == oracle.encode_u32(vals, w), (w, n)
+            blocks = (n + 31) // 32
+            assert bitpacked.encode(vals, w).tobytes() == oracle.bitpacked_encode_u32(vals, w, blocks * 4 * w).tobytes()
+    bools = rng.integers(0, 2, 77)
+    assert hybrid_rle.encode_bool(bools) == oracle.encode_bool(bools)
+    assert hybrid_rle.bitpacked_encode(bools) == oracle.bitmap_encode_bool(bools)
+
+
+def _runs_from_spec(spec):
+    return [HybridEncoded.Bitmap(bytes(r[1]), r[2]) if r[0] == "bitmap" else HybridEncoded.Repeated(bool(r[1]), r[2])
+            for r in spec]
+
+
+def test_filtered_runs(kats):
+    for c in kats["filtered_runs"]:
+        it = FilteredHybridBitmapIter(iter(_runs_from_spec(c["runs"])), [Interval(s, l) for s, l in c["intervals"]])
+        got = []
+        try:
+            for o in it:
+                if isinstance(o, FilteredHybridEncoded.Bitmap):
+                    got.append(["bitmap", list(o.values), o.offset, o.length])
+                elif isinstance(o, FilteredHybridEncoded.Repeated):
+                    got.append(["repeated", o.is_set, o.length])
+                else:
+                    got.append(["skipped", o.set_count])
+        except RuntimeError:
+            pass
+        assert got == c["expected"], c["src"]
+        assert it.len() == 0
+
+
+test_filtered_runs = pytest.mark.gpu(test_filtered_runs)  # Skipped(set) counts bits with the GPU BitmapIter
+
+
+def test_hybrid_rle_iter(oracle):
+    stream = bytes([0b00000101, 0b11101011, 0b00000010, 0b00010000, 1])
+    runs = list(HybridDecoderBitmapIter(stream, 20))
+    assert runs == [HybridEncoded.Bitmap(bytes([0b11101011, 0b00000010]), 16), HybridEncoded.Repeated(True, 4)]
+    assert [r.len() for r in HybridDecoderBitmapIter(stream, 10)] == [10]
+    assert [r.len() for r in HybridDecoderBitmapIter(stream, 100)] == [16, 8]  # no zero padding here
+    s, v = synth.def_levels_page(5, 20000)
+    got = list(HybridRleIter(hybrid_rle.Decoder(s, 1), len(v)))
+    st, expect, n = oracle.bitmap_runs(s, len(v))
+    assert st == 0 and n == len(got)
+    for g, e in zip(got, expect):
+        assert g.len() == e.length
+        assert isinstance(g, HybridEncoded.Bitmap) == (e.kind == 0)
+        if e.kind == 1:
+            assert g.is_set == bool(e.is_set)
+
+
+def test_slice_filtered_iter(kats):
+    c = kats["slice_filtered_iter"]
+    lo, hi = c["iter_range_inclusive"]
+    it = SliceFilteredIter(iter(range(lo, hi + 1)), [Interval(s, l) for s, l in c["intervals"]])
+    assert list(it) == [x for s, l in c["intervals"] for x in range(s, s + l)]
+    assert it.size_hint() == (0, 0)
+
+
+def test_partition_pages():
+    descs = np.zeros(10, dtype=PAGE_DESC_DTYPE)
+    descs["num_values"] = [100] * 10
+    assert partition_pages(descs, 1).tolist() == [0, 10]
+    assert partition_pages(descs, 2).tolist() == [0, 5, 10]
+    assert partition_pages(descs, 5).tolist() == [0, 2, 4, 6, 8, 10]
+    b = partition_pages(descs, 3).tolist()
+    assert b[0] == 0 and b[-1] == 10 and all(x <= y for x, y in zip(b, b[1:]))
+    assert max(y - x for x, y in zip(b, b[1:])) - min(y - x for x, y in zip(b, b[1:])) <= 1
+    descs["num_values"] = [1000, 1, 1, 1, 1, 1, 1, 1, 1, 992]
+    b = partition_pages(descs, 2).tolist()
+    assert b == [0, 1, 10] or b == [0, 2, 10] or b[1] in range(1, 10)
+    rng = np.random.default_rng(0)
+    for parts in (1, 2, 3, 4, 8, 16):
+        descs = np.zeros(rng.integers(1, 200), dtype=PAGE_DESC_DTYPE)
+        descs["num_values"] = rng.integers(0, 1 << 20, len(descs))
+        b = partition_pages(descs, parts)
+        assert b[0] == 0 and b[-1] == len(descs) and (np.diff(b) >= 0).all()
+        loads = [int(descs["num_values"][b[i]:b[i + 1]].sum()) for i in range(parts)]
+        # contiguous split: no part exceeds the ideal share by more than one page
+        assert max(loads) <= descs["num_values"].sum() / parts + descs["num_values"].max()
+    assert partition_pages(np.zeros(0, dtype=PAGE_DESC_DTYPE), 4).tolist() == [0, 0, 0, 0, 0]

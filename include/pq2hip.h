@@ -67,6 +67,13 @@ const char *pq2_strerror(int32_t status);
 /* message of the last failing call on this context ("" if none) */
 const char *pq2_last_error(const pq2_ctx *ctx);
 
+/* Kernel timing for benchmarks (no counterpart in the reference).  While
+ * enabled, every batch records HIP events on its stream around the parse and
+ * the expand kernel; pq2_ctx_kernel_times waits for them, returns the summed
+ * durations in milliseconds with the number of batches, and resets the sums. */
+int32_t pq2_ctx_enable_profiling(pq2_ctx *ctx, int32_t on);
+int32_t pq2_ctx_kernel_times(pq2_ctx *ctx, double *parse_ms, double *expand_ms, uint64_t *batches);
+
 /* ---- hybrid RLE / bit-packed decode -------------------------------------- */
 
 /* Replaces, for every page i of the batch,

@@ -52,6 +52,8 @@ SIGNATURES = {
     "pq2_ctx_destroy": (C.c_int32, [C.c_void_p]),
     "pq2_strerror": (C.c_char_p, [C.c_int32]),
     "pq2_last_error": (C.c_char_p, [C.c_void_p]),
+    "pq2_ctx_enable_profiling": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "pq2_ctx_kernel_times": (C.c_int32, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), u64p]),
     "pq2_decode_batch_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p,
                                              C.c_uint64, C.c_void_p, C.c_void_p]),
     "pq2_fetch_status": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64]),
@@ -140,6 +142,16 @@ class Context:
     def _check(self, st):
         if st != OK:
             raise_for_status(st, lib().pq2_last_error(self._h).decode() or lib().pq2_strerror(st).decode())
+
+    # ---- kernel timing ---------------------------------------------------------
+    def enable_profiling(self, on=True):
+        self._check(lib().pq2_ctx_enable_profiling(self._h, int(on)))
+
+    def kernel_times(self):
+        """(parse_ms, expand_ms, batches) summed since the last call."""
+        a, b, n = C.c_double(), C.c_double(), C.c_uint64()
+        self._check(lib().pq2_ctx_kernel_times(self._h, C.byref(a), C.byref(b), C.byref(n)))
+        return a.value, b.value, n.value
 
     # ---- device-resident batch decode --------------------------------------
     def decode_batch_device(self, d_in_ptr, in_bytes, descs, d_out_ptr, out_values, stream=0, want_status=True):

@@ -60,6 +60,12 @@ struct pq2_ctx {
     uint64_t last_n_pages = 0;
     hipStream_t last_stream = nullptr;
     bool busy = false;  // a batch may still be running on last_stream
+    // optional kernel timing (pq2_ctx_enable_profiling): events around parse and expand of every batch
+    bool profiling = false;
+    struct Stamp {
+        hipEvent_t e[3];
+    };
+    std::vector<Stamp> stamps;
     // host-buffer path
     DevBuf d_in, d_out;
     hipStream_t copy_streams[3] = {nullptr, nullptr, nullptr};
@@ -172,10 +178,20 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
 
     const PageDev *d_pages = static_cast<const PageDev *>(ctx->d_meta.ptr);
     const uint32_t *d_tile_base = reinterpret_cast<const uint32_t *>(d_pages + n_pages);
+    pq2_ctx::Stamp stamp{};
+    if (ctx->profiling) {
+        for (auto &e : stamp.e) PQ2_HIP(ctx, hipEventCreate(&e));
+        PQ2_HIP(ctx, hipEventRecord(stamp.e[0], stream));
+    }
     PQ2_HIP(ctx, pq2_launch_parse(d_pages, static_cast<uint32_t>(n_pages), ctx->d_resume.ptr,
                                   static_cast<int32_t *>(ctx->d_status.ptr), stream));
+    if (ctx->profiling) PQ2_HIP(ctx, hipEventRecord(stamp.e[1], stream));
     PQ2_HIP(ctx, pq2_launch_expand(d_pages, d_tile_base, static_cast<uint32_t>(n_pages), static_cast<uint32_t>(tiles),
                                    ctx->d_resume.ptr, stream));
+    if (ctx->profiling) {
+        PQ2_HIP(ctx, hipEventRecord(stamp.e[2], stream));
+        ctx->stamps.push_back(stamp);
+    }
     return PQ2_OK;
 }
 
@@ -220,6 +236,8 @@ int32_t pq2_ctx_destroy(pq2_ctx *ctx) {
         if (b->ptr) (void)hipFree(b->ptr);
     if (ctx->h_meta) (void)hipHostFree(ctx->h_meta);
     if (ctx->meta_copied) (void)hipEventDestroy(ctx->meta_copied);
+    for (auto &s : ctx->stamps)
+        for (auto &e : s.e) (void)hipEventDestroy(e);
     for (int i = 0; i < 3; ++i) {
         if (ctx->copy_streams[i]) (void)hipStreamDestroy(ctx->copy_streams[i]);
         if (ctx->chunk_done[i]) (void)hipEventDestroy(ctx->chunk_done[i]);
@@ -242,6 +260,30 @@ const char *pq2_strerror(int32_t status) {
 }
 
 const char *pq2_last_error(const pq2_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+int32_t pq2_ctx_enable_profiling(pq2_ctx *ctx, int32_t on) {
+    if (!ctx) return PQ2_INVALID_PARAMETER;
+    ctx->profiling = on != 0;
+    return PQ2_OK;
+}
+
+int32_t pq2_ctx_kernel_times(pq2_ctx *ctx, double *parse_ms, double *expand_ms, uint64_t *batches) {
+    if (!ctx || !parse_ms || !expand_ms || !batches) return PQ2_INVALID_PARAMETER;
+    PQ2_HIP(ctx, hipSetDevice(ctx->device));
+    *parse_ms = *expand_ms = 0.0;
+    *batches = ctx->stamps.size();
+    for (auto &s : ctx->stamps) {
+        PQ2_HIP(ctx, hipEventSynchronize(s.e[2]));
+        float a = 0.f, b = 0.f;
+        PQ2_HIP(ctx, hipEventElapsedTime(&a, s.e[0], s.e[1]));
+        PQ2_HIP(ctx, hipEventElapsedTime(&b, s.e[1], s.e[2]));
+        *parse_ms += a;
+        *expand_ms += b;
+        for (auto &e : s.e) (void)hipEventDestroy(e);
+    }
+    ctx->stamps.clear();
+    return PQ2_OK;
+}
 
 int32_t pq2_decode_batch_device(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const pq2_page_desc *descs,
                                 uint64_t n_pages, uint32_t *d_out, uint64_t out_values, int32_t *status,

@@ -18,9 +18,10 @@
 #include "../../include/pq2hip.h"
 
 extern "C" {
-hipError_t pq2_launch_parse(const void *pages, uint32_t n_pages, void *resume, int32_t *status, hipStream_t stream);
-hipError_t pq2_launch_expand(const void *pages, const uint32_t *tile_base, uint32_t n_pages, uint32_t n_tiles,
-                             const void *resume, hipStream_t stream);
+hipError_t pq2_launch_parse(const void *pages, uint32_t n_pages, void *resume, uint32_t *tile_page, int32_t *status,
+                            hipStream_t stream);
+hipError_t pq2_launch_expand(const void *pages, const uint32_t *tile_page, uint32_t n_tiles, const void *resume,
+                             hipStream_t stream);
 hipError_t pq2_launch_bitunpack(const void *d_packed, uint32_t packed_len, uint32_t num_bits, uint32_t length,
                                 uint32_t *d_out, hipStream_t stream);
 }
@@ -50,12 +51,12 @@ struct DevBuf {
 struct pq2_ctx {
     int device = 0;
     std::string last_error;
-    // per-batch metadata: [PageDev x n][tile_base x (n+1)] in one pinned block, mirrored on the device
+    // per-batch metadata: [PageDev x n] in one pinned block, mirrored on the device
     void *h_meta = nullptr;
     size_t h_meta_cap = 0;
     hipEvent_t meta_copied = nullptr;  // the previous upload has left h_meta
     bool meta_in_flight = false;
-    DevBuf d_meta, d_status, d_resume;
+    DevBuf d_meta, d_status, d_resume, d_tile_page;
     std::vector<int32_t> host_status;  // statuses decided on the host (bad num_bits)
     uint64_t last_n_pages = 0;
     hipStream_t last_stream = nullptr;
@@ -131,7 +132,7 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
     if (n_pages == 0) return PQ2_OK;
     ctx->busy = true;
 
-    const size_t meta_bytes = n_pages * sizeof(PageDev) + (n_pages + 1) * sizeof(uint32_t);
+    const size_t meta_bytes = n_pages * sizeof(PageDev);
     int32_t st = reserve_pinned(ctx, meta_bytes);
     if (st) return st;
     if (ctx->meta_in_flight) {  // the previous batch's upload still reads the pinned block
@@ -139,7 +140,6 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
         ctx->meta_in_flight = false;
     }
     PageDev *pages = static_cast<PageDev *>(ctx->h_meta);
-    uint32_t *tile_base = reinterpret_cast<uint32_t *>(pages + n_pages);
 
     uint64_t tiles = 0;
     for (uint64_t i = 0; i < n_pages; ++i) {
@@ -161,33 +161,31 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
             p.num_values = 0;
         }
         p.tile_base = static_cast<uint32_t>(tiles);
-        tile_base[i] = static_cast<uint32_t>(tiles);
         tiles += (p.num_values + kTileValues - 1) / kTileValues;
         if (tiles > 0x7fffffffull) return fail(ctx, PQ2_INVALID_PARAMETER, "batch too large for one launch");
     }
-    tile_base[n_pages] = static_cast<uint32_t>(tiles);
     if ((reinterpret_cast<uintptr_t>(d_out) & 3u) != 0) return fail(ctx, PQ2_INVALID_PARAMETER, "d_out misaligned");
 
     if ((st = reserve(ctx, ctx->d_meta, meta_bytes))) return st;
     if ((st = reserve(ctx, ctx->d_status, n_pages * sizeof(int32_t)))) return st;
     if ((st = reserve(ctx, ctx->d_resume, std::max<uint64_t>(tiles, 1) * kBlocksPerTile * 8))) return st;
+    if ((st = reserve(ctx, ctx->d_tile_page, std::max<uint64_t>(tiles, 1) * sizeof(uint32_t)))) return st;
 
     PQ2_HIP(ctx, hipMemcpyAsync(ctx->d_meta.ptr, ctx->h_meta, meta_bytes, hipMemcpyHostToDevice, stream));
     PQ2_HIP(ctx, hipEventRecord(ctx->meta_copied, stream));
     ctx->meta_in_flight = true;
 
     const PageDev *d_pages = static_cast<const PageDev *>(ctx->d_meta.ptr);
-    const uint32_t *d_tile_base = reinterpret_cast<const uint32_t *>(d_pages + n_pages);
+    uint32_t *d_tile_page = static_cast<uint32_t *>(ctx->d_tile_page.ptr);
     pq2_ctx::Stamp stamp{};
     if (ctx->profiling) {
         for (auto &e : stamp.e) PQ2_HIP(ctx, hipEventCreate(&e));
         PQ2_HIP(ctx, hipEventRecord(stamp.e[0], stream));
     }
-    PQ2_HIP(ctx, pq2_launch_parse(d_pages, static_cast<uint32_t>(n_pages), ctx->d_resume.ptr,
+    PQ2_HIP(ctx, pq2_launch_parse(d_pages, static_cast<uint32_t>(n_pages), ctx->d_resume.ptr, d_tile_page,
                                   static_cast<int32_t *>(ctx->d_status.ptr), stream));
     if (ctx->profiling) PQ2_HIP(ctx, hipEventRecord(stamp.e[1], stream));
-    PQ2_HIP(ctx, pq2_launch_expand(d_pages, d_tile_base, static_cast<uint32_t>(n_pages), static_cast<uint32_t>(tiles),
-                                   ctx->d_resume.ptr, stream));
+    PQ2_HIP(ctx, pq2_launch_expand(d_pages, d_tile_page, static_cast<uint32_t>(tiles), ctx->d_resume.ptr, stream));
     if (ctx->profiling) {
         PQ2_HIP(ctx, hipEventRecord(stamp.e[2], stream));
         ctx->stamps.push_back(stamp);
@@ -232,7 +230,7 @@ int32_t pq2_ctx_destroy(pq2_ctx *ctx) {
     if (!ctx) return PQ2_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    for (DevBuf *b : {&ctx->d_meta, &ctx->d_status, &ctx->d_resume, &ctx->d_in, &ctx->d_out})
+    for (DevBuf *b : {&ctx->d_meta, &ctx->d_status, &ctx->d_resume, &ctx->d_tile_page, &ctx->d_in, &ctx->d_out})
         if (b->ptr) (void)hipFree(b->ptr);
     if (ctx->h_meta) (void)hipHostFree(ctx->h_meta);
     if (ctx->meta_copied) (void)hipEventDestroy(ctx->meta_copied);

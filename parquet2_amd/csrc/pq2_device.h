@@ -56,66 +56,44 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(uint64_t base16, uin
 
 __device__ __forceinline__ uint32_t ceil8(uint32_t v) { return (v + 7u) >> 3; }
 
-// Decodes the run whose header starts at a-offset `pos`.  `rd(a)` returns the
-// aligned dword at a-offset `a` (a % 4 == 0); everything here is wave-uniform.
-//
-// Follows hybrid_rle::Decoder::next (src/encoding/hybrid_rle/decoder.rs:30-64),
-// uleb128::decode (src/encoding/uleb128.rs:3-23) and read_next
-// (src/encoding/hybrid_rle/mod.rs:41-64):
-//   - an exhausted stream, or a header that consumes the last byte, ends the
-//     stream (kEnd): the caller pads with zeros (mod.rs:95);
-//   - bit-packed: bytes = min((ind >> 1) * w, left); values = min(bytes*8/w, remaining);
-//   - RLE: the value is the first min(4, ceil8(w)) bytes, little endian, not
-//     masked; fewer than ceil8(w) bytes left is a panic in the reference.
+// Rare headers: varints of 3..10 bytes, and bit-packed runs cut by the end of
+// the stream.  Same contract as decode_run below.
 template <typename Rd>
-__device__ __forceinline__ RunInfo decode_run(Rd rd, uint32_t pos, uint32_t end, uint32_t w, uint32_t remaining) {
+__device__ inline RunInfo decode_run_slow(Rd rd, uint32_t pos, uint32_t end, uint32_t w, uint32_t remaining) {
     RunInfo r;
     r.kind = kEnd;
     r.count = 0;
     r.payload = 0;
     r.value = 0;
     r.next = end;
-    if (pos >= end) return r;
-
     const uint32_t a0 = pos & ~3u;
     const uint32_t sh = (pos & 3u) * 8u;
     const uint32_t d0 = rd(a0), d1 = rd(a0 + 4), d2 = rd(a0 + 8), d3 = rd(a0 + 12);
-    // 12 stream bytes starting at pos
-    const uint32_t x0 = __builtin_amdgcn_alignbit(d1, d0, sh);
+    const uint32_t x0 = __builtin_amdgcn_alignbit(d1, d0, sh);  // 12 stream bytes starting at pos
     const uint32_t x1 = __builtin_amdgcn_alignbit(d2, d1, sh);
     const uint32_t x2 = __builtin_amdgcn_alignbit(d3, d2, sh);
 
-    uint64_t ind;
-    uint32_t c;
-    if ((x0 & 0x80u) == 0) {  // one-byte header: by far the common case
-        ind = x0 & 0x7fu;
-        c = 1;
-    } else if ((x0 & 0x8000u) == 0) {
-        ind = (x0 & 0x7fu) | ((x0 >> 1) & 0x3f80u);
-        c = 2;
-    } else {
-        ind = 0;
-        c = 0;
-        bool done = false;
-        for (uint32_t i = 0; i < 10 && !done; ++i) {
-            if (pos + i >= end) return r;  // varint runs into the end of the stream: consumed == len
-            const uint32_t word = i < 4 ? x0 : (i < 8 ? x1 : x2);
-            const uint32_t b = (word >> ((i & 3u) * 8u)) & 0xffu;
-            c = i + 1;
-            if (i == 9 && b > 1) {  // uleb128.rs:10-12
-                r.kind = kPanic;
-                return r;
-            }
-            ind |= (uint64_t)(b & 0x7fu) << (7u * i);
-            done = (b & 0x80u) == 0;
+    // uleb128::decode, src/encoding/uleb128.rs:3-23
+    uint64_t ind = 0;
+    uint32_t c = 0;
+    bool done = false;
+    for (uint32_t i = 0; i < 10 && !done; ++i) {
+        if (pos + i >= end) return r;  // the varint runs into the end of the stream: consumed == len
+        const uint32_t word = i < 4 ? x0 : (i < 8 ? x1 : x2);
+        const uint32_t b = (word >> ((i & 3u) * 8u)) & 0xffu;
+        c = i + 1;
+        if (i == 9 && b > 1) {  // uleb128.rs:10-12
+            r.kind = kPanic;
+            return r;
         }
+        ind |= (uint64_t)(b & 0x7fu) << (7u * i);
+        done = (b & 0x80u) == 0;
     }
     const uint32_t p = pos + c;
-    if (p >= end) return r;  // decoder.rs:44-46 (also covers a varint cut by the end of the stream)
+    if (p >= end) return r;  // src/encoding/hybrid_rle/decoder.rs:44-46
     const uint32_t left = end - p;
     const uint64_t n = ind >> 1;
     if (ind & 1u) {
-        // bit-packed run
         if ((n >> 59) != 0 && n > 0xffffffffffffffffull / w) {  // (ind >> 1) * num_bits overflows usize
             r.kind = kPanic;
             return r;
@@ -125,7 +103,7 @@ __device__ __forceinline__ RunInfo decode_run(Rd rd, uint32_t pos, uint32_t end,
         uint64_t k;
         if (bytes > left) {  // decoder.rs:51 clamp: only whole values inside the remaining bytes
             nbytes = left;
-            k = (uint64_t)(left / w) * 8u + ((left % w) * 8u) / w;  // left * 8 / w without 64-bit division
+            k = (uint64_t)(left / w) * 8u + ((left % w) * 8u) / w;  // left * 8 / w
         } else {
             nbytes = (uint32_t)bytes;
             k = n * 8u;
@@ -140,17 +118,8 @@ __device__ __forceinline__ RunInfo decode_run(Rd rd, uint32_t pos, uint32_t end,
             r.kind = kPanic;
             return r;
         }
-        uint32_t v;
-        if (c < 4)
-            v = __builtin_amdgcn_alignbit(x1, x0, c * 8u);
-        else if (c < 8)
-            v = __builtin_amdgcn_alignbit(x2, x1, (c - 4u) * 8u);
-        else if (c == 8)
-            v = x2;
-        else {  // 9- or 10-byte header: the value lies beyond the 12 bytes fetched above
-            const uint32_t b0 = p & ~3u;
-            v = __builtin_amdgcn_alignbit(rd(b0 + 4), rd(b0), (p & 3u) * 8u);
-        }
+        const uint32_t b0 = p & ~3u;
+        uint32_t v = __builtin_amdgcn_alignbit(rd(b0 + 4), rd(b0), (p & 3u) * 8u);
         if (rb < 4) v &= (1u << (rb * 8u)) - 1u;
         r.kind = kRle;
         r.count = n < remaining ? (uint32_t)n : remaining;
@@ -160,16 +129,72 @@ __device__ __forceinline__ RunInfo decode_run(Rd rd, uint32_t pos, uint32_t end,
     return r;
 }
 
-// ---- emission ---------------------------------------------------------------
-// A wave writes `count` values starting at `out` (4-byte aligned).  Lanes own
-// 16-byte-aligned groups of 4 values, so full groups are single dwordx4 stores
-// and one store instruction of the wave covers 1 KiB of contiguous output;
-// groups cut by the start or the end of the span fall back to dword stores.
-
-__device__ __forceinline__ int32_t first_group(const uint32_t *out, uint32_t lane) {
-    const uint32_t mis = (uint32_t)(((uintptr_t)out >> 2) & 3u);
-    return (int32_t)(lane * 4u) - (int32_t)mis;
+// Decodes the run whose header starts at a-offset `pos`.  `rd(a)` returns the
+// aligned dword at a-offset `a` (a % 4 == 0); up to 24 bytes from pos & ~3 are
+// read.  Everything here is wave-uniform.
+//
+// Follows hybrid_rle::Decoder::next (src/encoding/hybrid_rle/decoder.rs:30-64),
+// uleb128::decode (src/encoding/uleb128.rs:3-23) and read_next
+// (src/encoding/hybrid_rle/mod.rs:41-64):
+//   - an exhausted stream, or a header that consumes the last byte, ends the
+//     stream (kEnd): the caller pads with zeros (mod.rs:95);
+//   - bit-packed: bytes = min((ind >> 1) * w, left); values = min(bytes*8/w, remaining);
+//   - RLE: the value is the first min(4, ceil8(w)) bytes, little endian, not
+//     masked; fewer than ceil8(w) bytes left is a panic in the reference.
+// Headers of one or two bytes whose run lies inside the stream take the short
+// path below; everything else goes through decode_run_slow.
+template <typename Rd>
+__device__ __forceinline__ RunInfo decode_run(Rd rd, uint32_t pos, uint32_t end, uint32_t w, uint32_t remaining) {
+    RunInfo r;
+    if (pos >= end) {
+        r.kind = kEnd;
+        r.count = 0;
+        r.payload = 0;
+        r.value = 0;
+        r.next = end;
+        return r;
+    }
+    const uint32_t a0 = pos & ~3u;
+    const uint32_t sh = (pos & 3u) * 8u;
+    const uint32_t d0 = rd(a0), d1 = rd(a0 + 4), d2 = rd(a0 + 8);
+    const uint32_t x0 = __builtin_amdgcn_alignbit(d1, d0, sh);  // stream bytes pos .. pos+3
+    const uint32_t x1 = __builtin_amdgcn_alignbit(d2, d1, sh);  // stream bytes pos+4 .. pos+7
+    uint32_t ind, c, rest;  // header value, header bytes, the 4 stream bytes after the header
+    if ((x0 & 0x80u) == 0) {
+        ind = x0 & 0x7fu;
+        c = 1;
+        rest = __builtin_amdgcn_alignbit(x1, x0, 8);
+    } else if ((x0 & 0x8000u) == 0) {
+        ind = (x0 & 0x7fu) | ((x0 >> 1) & 0x3f80u);
+        c = 2;
+        rest = __builtin_amdgcn_alignbit(x1, x0, 16);
+    } else {
+        return decode_run_slow(rd, pos, end, w, remaining);
+    }
+    const uint32_t p = pos + c;
+    const uint32_t n = ind >> 1;
+    if (ind & 1u) {
+        const uint32_t bytes = n * w;  // < 2^13 * 32
+        if (p >= end || bytes > end - p) return decode_run_slow(rd, pos, end, w, remaining);
+        const uint32_t k = n * 8u;
+        r.kind = kBitpacked;
+        r.count = k < remaining ? k : remaining;
+        r.payload = p;
+        r.value = 0;
+        r.next = p + bytes;
+    } else {
+        const uint32_t rb = ceil8(w);
+        if (p >= end || rb > end - p) return decode_run_slow(rd, pos, end, w, remaining);
+        r.kind = kRle;
+        r.count = n < remaining ? n : remaining;
+        r.payload = 0;
+        r.value = rb < 4 ? (rest & ((1u << (rb * 8u)) - 1u)) : rest;
+        r.next = p + rb;
+    }
+    return r;
 }
+
+// ---- stores -------------------------------------------------------------------
 
 __device__ __forceinline__ void store4(u32x4 v, uint32_t *p) {
 #ifdef PQ2_NT_STORES
@@ -179,40 +204,144 @@ __device__ __forceinline__ void store4(u32x4 v, uint32_t *p) {
 #endif
 }
 
+// A wave writes `count` copies of v at `out` (4-byte aligned).  Short spans go
+// out one value per lane; long ones as 16-byte-aligned dwordx4 stores (1 KiB
+// per wave instruction) with the unaligned head and tail done by a few lanes.
 __device__ __forceinline__ void emit_rle(uint32_t v, uint32_t *out, uint32_t count, uint32_t lane) {
+    if (count < 128u) {
+        for (uint32_t i = lane; i < count; i += 64u) out[i] = v;
+        return;
+    }
+    const uint32_t head = (4u - (uint32_t)(((uintptr_t)out >> 2) & 3u)) & 3u;
+    if (lane < head) out[lane] = v;
+    const uint32_t groups = (count - head) >> 2;
     const u32x4 vv = {v, v, v, v};
-    for (int32_t r = first_group(out, lane); r < (int32_t)count; r += 256) {
-        if (r >= 0 && r + 4 <= (int32_t)count) {
-            store4(vv, out + r);
-        } else {
+    for (uint32_t g = lane; g < groups; g += 64u) store4(vv, out + head + 4u * g);
+    const uint32_t tail = head + 4u * groups;
+    if (lane < count - tail) out[tail + lane] = v;
+}
+
+// ---- LDS-staged stream window --------------------------------------------------
+// Each wave of expand_kernel owns kWinBytes of LDS holding stream bytes
+// [lo, hi) (a-coordinates, lo 16-byte aligned).  A refill is 1..4 coalesced
+// dwordx4 loads of the whole wave (1 KiB each) -- one memory round trip --
+// after which run headers and bit-packed fields are read from LDS.  The region
+// is private to the wave: LDS operations of one wave execute in order, so no
+// barrier is needed between the fill and the reads.
+constexpr uint32_t kWinBytes = 4096;
+
+struct Window {
+    uint32_t lo, hi;  // resident a-offsets [lo, hi)
+    uint8_t *lds;     // this wave's kWinBytes
+
+    __device__ __forceinline__ void fill(__amdgpu_buffer_rsrc_t rsrc, uint32_t from, uint32_t need, uint32_t lane) {
+        lo = from & ~15u;
+        uint32_t pieces = (need + (from & 15u) + 1023u) >> 10;
+        pieces = pieces < 1u ? 1u : (pieces > 4u ? 4u : pieces);
+        u32x4 v[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int32_t idx = r + i;
-                if (idx >= 0 && idx < (int32_t)count) out[idx] = v;
-            }
+        for (uint32_t i = 0; i < 4; ++i)
+            if (i < pieces) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lo + i * 1024u + lane * 16u, 0, 0);
+#pragma unroll
+        for (uint32_t i = 0; i < 4; ++i)
+            if (i < pieces) *(u32x4 *)(lds + i * 1024u + lane * 16u) = v[i];
+        hi = lo + pieces * 1024u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    __device__ __forceinline__ bool holds(uint32_t a_lo, uint32_t a_hi) const { return a_lo >= lo && a_hi <= hi; }
+    __device__ __forceinline__ uint32_t dword(uint32_t a) const { return *(const uint32_t *)(lds + (a - lo)); }
+};
+
+// Bit position, inside the window's LDS image, of the run-internal value
+// `v_begin`: every later value i of the span sits at span_bit0 + i * W.  The
+// caller guarantees the span's bytes are resident, so the result is < 2^16.
+__device__ __forceinline__ uint32_t span_bit0(const Window &win, uint32_t payload, uint32_t v_begin, uint32_t w) {
+    return (payload + (v_begin >> 3) * w - win.lo) * 8u + (v_begin & 7u) * w;
+}
+
+// One W-bit field at LDS bit position `bit` (LSB-first, src/encoding/bitpacked/unpack.rs:40-67).
+template <int W>
+__device__ __forceinline__ uint32_t field_at(const uint8_t *lds, uint32_t bit) {
+    const uint32_t *src = (const uint32_t *)(lds + ((bit >> 3) & ~3u));
+    const uint32_t x = __builtin_amdgcn_alignbit(src[1], src[0], bit & 31u);
+    constexpr uint32_t mask = W == 32 ? 0xffffffffu : ((1u << (W & 31)) - 1u);
+    return x & mask;
+}
+
+// Four consecutive W-bit fields starting at LDS bit position `bit`: the lane
+// reads the aligned dwords holding its 4*W bits, funnel-shifts them down to
+// bit 0, and then every field sits at a compile-time position.
+template <int W>
+__device__ __forceinline__ u32x4 fields4_at(const uint8_t *lds, uint32_t bit) {
+    constexpr int NY = (4 * W + 31) / 32;  // dwords holding 4 fields once aligned to bit 0
+    const uint32_t *src = (const uint32_t *)(lds + ((bit >> 3) & ~3u));
+    const uint32_t s = bit & 31u;
+    uint32_t x[NY + 1];
+#pragma unroll
+    for (int i = 0; i <= NY; ++i) x[i] = src[i];
+    uint32_t y[NY];
+#pragma unroll
+    for (int i = 0; i < NY; ++i) y[i] = __builtin_amdgcn_alignbit(x[i + 1], x[i], s);
+    constexpr uint32_t mask = W == 32 ? 0xffffffffu : ((1u << (W & 31)) - 1u);
+    uint32_t o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int lo = (i * W) >> 5;
+        const int shf = (i * W) & 31;
+        if (shf + W <= 32) {
+            o[i] = W == 32 ? y[lo] : ((y[lo] >> shf) & mask);
+        } else {
+            o[i] = __builtin_amdgcn_alignbit(y[lo + 1 < NY ? lo + 1 : lo], y[lo], shf) & mask;
         }
+    }
+    const u32x4 res = {o[0], o[1], o[2], o[3]};
+    return res;
+}
+
+// `count` bit-packed values whose bytes are resident in the window, first one
+// at LDS bit position bit0.  Same store shapes as emit_rle.
+template <int W>
+__device__ __forceinline__ void emit_bp_lds(const uint8_t *lds, uint32_t bit0, uint32_t *out, uint32_t count,
+                                            uint32_t lane) {
+    if (count < 128u) {
+        for (uint32_t i = lane; i < count; i += 64u) out[i] = field_at<W>(lds, bit0 + i * (uint32_t)W);
+        return;
+    }
+    const uint32_t head = (4u - (uint32_t)(((uintptr_t)out >> 2) & 3u)) & 3u;
+    if (lane < head) out[lane] = field_at<W>(lds, bit0 + lane * (uint32_t)W);
+    const uint32_t groups = (count - head) >> 2;
+    const uint32_t body0 = bit0 + head * (uint32_t)W;
+    for (uint32_t g = lane; g < groups; g += 64u)
+        store4(fields4_at<W>(lds, body0 + g * (4u * (uint32_t)W)), out + head + 4u * g);
+    const uint32_t tail = head + 4u * groups;
+    if (lane < count - tail) out[tail + lane] = field_at<W>(lds, bit0 + (tail + lane) * (uint32_t)W);
+}
+
+// Width dispatch: one specialised body per bit width 1..32.
+__device__ __forceinline__ void emit_bp_lds_dispatch(uint32_t w, const uint8_t *lds, uint32_t bit0, uint32_t *out,
+                                                     uint32_t count, uint32_t lane) {
+    switch (w) {
+#define PQ2_W(N)                                       \
+    case N:                                            \
+        emit_bp_lds<N>(lds, bit0, out, count, lane);   \
+        break;
+        PQ2_W(1) PQ2_W(2) PQ2_W(3) PQ2_W(4) PQ2_W(5) PQ2_W(6) PQ2_W(7) PQ2_W(8)
+        PQ2_W(9) PQ2_W(10) PQ2_W(11) PQ2_W(12) PQ2_W(13) PQ2_W(14) PQ2_W(15) PQ2_W(16)
+        PQ2_W(17) PQ2_W(18) PQ2_W(19) PQ2_W(20) PQ2_W(21) PQ2_W(22) PQ2_W(23) PQ2_W(24)
+        PQ2_W(25) PQ2_W(26) PQ2_W(27) PQ2_W(28) PQ2_W(29) PQ2_W(30) PQ2_W(31) PQ2_W(32)
+#undef PQ2_W
+        default:
+            break;
     }
 }
 
-// One value at run-internal index v (any width 1..32).
-__device__ __forceinline__ uint32_t extract1(__amdgpu_buffer_rsrc_t rsrc, uint32_t payload, uint32_t v, uint32_t w) {
-    const uint32_t byte_off = payload + (v >> 3) * w;
-    const uint32_t bit_in = (byte_off & 3u) * 8u + (v & 7u) * w;
-    const uint32_t d = (byte_off >> 2) + (bit_in >> 5);
-    const uint32_t s = bit_in & 31u;
-    const uint32_t lo = __builtin_amdgcn_raw_buffer_load_b32(rsrc, d * 4u, 0, 0);
-    const uint32_t hi = __builtin_amdgcn_raw_buffer_load_b32(rsrc, d * 4u + 4u, 0, 0);
-    const uint32_t x = __builtin_amdgcn_alignbit(hi, lo, s);
-    return w == 32 ? x : (x & ((1u << w) - 1u));
-}
+// ---- direct-from-memory extraction (bitunpack_kernel: no headers, no staging) -------------
 
-// Four consecutive values starting at run-internal index v, width W known at
-// compile time: the lane loads the aligned dwords that hold its 4*W bits,
-// funnel-shifts them down to bit 0 and then every field sits at a constant
-// position.  LSB-first layout as src/encoding/bitpacked/unpack.rs:40-67.
+// Four consecutive values starting at run-internal index v, straight from the buffer.
 template <int W>
 __device__ __forceinline__ u32x4 extract4(__amdgpu_buffer_rsrc_t rsrc, uint32_t payload, uint32_t v) {
-    constexpr int NY = (4 * W + 31) / 32;  // dwords holding 4 values once aligned to bit 0
+    constexpr int NY = (4 * W + 31) / 32;
     const uint32_t byte_off = payload + (v >> 3) * (uint32_t)W;
     const uint32_t bit_in = (byte_off & 3u) * 8u + (v & 7u) * (uint32_t)W;
     const uint32_t d = (byte_off >> 2) + (bit_in >> 5);
@@ -239,24 +368,30 @@ __device__ __forceinline__ u32x4 extract4(__amdgpu_buffer_rsrc_t rsrc, uint32_t 
     return res;
 }
 
+__device__ __forceinline__ uint32_t extract1(__amdgpu_buffer_rsrc_t rsrc, uint32_t payload, uint32_t v, uint32_t w) {
+    const uint32_t byte_off = payload + (v >> 3) * w;
+    const uint32_t bit_in = (byte_off & 3u) * 8u + (v & 7u) * w;
+    const uint32_t d = (byte_off >> 2) + (bit_in >> 5);
+    const uint32_t s = bit_in & 31u;
+    const uint32_t lo = __builtin_amdgcn_raw_buffer_load_b32(rsrc, d * 4u, 0, 0);
+    const uint32_t hi = __builtin_amdgcn_raw_buffer_load_b32(rsrc, d * 4u + 4u, 0, 0);
+    const uint32_t x = __builtin_amdgcn_alignbit(hi, lo, s);
+    return w == 32 ? x : (x & ((1u << w) - 1u));
+}
+
 template <int W>
 __device__ __forceinline__ void emit_bp(__amdgpu_buffer_rsrc_t rsrc, uint32_t payload, uint32_t v_begin,
                                         uint32_t *out, uint32_t count, uint32_t lane) {
-    for (int32_t r = first_group(out, lane); r < (int32_t)count; r += 256) {
-        if (r >= 0 && r + 4 <= (int32_t)count) {
-            const u32x4 vals = extract4<W>(rsrc, payload, v_begin + (uint32_t)r);
-            store4(vals, out + r);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int32_t idx = r + i;
-                if (idx >= 0 && idx < (int32_t)count) out[idx] = extract1(rsrc, payload, v_begin + (uint32_t)idx, W);
-            }
-        }
-    }
+    const uint32_t head = (4u - (uint32_t)(((uintptr_t)out >> 2) & 3u)) & 3u;
+    const uint32_t h = head < count ? head : count;
+    if (lane < h) out[lane] = extract1(rsrc, payload, v_begin + lane, W);
+    const uint32_t groups = (count - h) >> 2;
+    for (uint32_t g = lane; g < groups; g += 64u)
+        store4(extract4<W>(rsrc, payload, v_begin + h + 4u * g), out + h + 4u * g);
+    const uint32_t tail = h + 4u * groups;
+    if (lane < count - tail) out[tail + lane] = extract1(rsrc, payload, v_begin + tail + lane, W);
 }
 
-// Width dispatch: one specialised body per bit width 1..32.
 __device__ __forceinline__ void emit_bp_dispatch(uint32_t w, __amdgpu_buffer_rsrc_t rsrc, uint32_t payload,
                                                  uint32_t v_begin, uint32_t *out, uint32_t count, uint32_t lane) {
     switch (w) {

@@ -27,7 +27,8 @@ constexpr uint32_t kRing = 2 * kHalf;
 // parse_kernel
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void parse_kernel(const PageDev *__restrict__ pages, uint32_t n_pages,
-                                                   Resume *__restrict__ resume, int32_t *__restrict__ status) {
+                                                   Resume *__restrict__ resume, uint32_t *__restrict__ tile_page,
+                                                   int32_t *__restrict__ status) {
     // ring[a & (kRing-1)] holds stream byte a for a in [win_lo, win_lo + kRing)
     __shared__ __attribute__((aligned(16))) uint8_t ring[kRing];
 
@@ -43,6 +44,8 @@ __global__ __launch_bounds__(64) void parse_kernel(const PageDev *__restrict__ p
     const uint32_t w = pg.num_bits;
     const uint32_t n_blocks = (n + kBlockValues - 1) / kBlockValues;
     Resume *const entries = resume + (size_t)pg.tile_base * kBlocksPerTile;
+    // expand_kernel finds its page through tile_page[tile]
+    for (uint32_t t = lane; t < (n_blocks + kBlocksPerTile - 1) / kBlocksPerTile; t += 64) tile_page[pg.tile_base + t] = page;
 
     // fills entries [from, n_blocks) with "stream exhausted"
     auto fill_end = [&](uint32_t from) {
@@ -136,23 +139,16 @@ __global__ __launch_bounds__(64) void parse_kernel(const PageDev *__restrict__ p
 // ---------------------------------------------------------------------------
 // expand_kernel
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void expand_kernel(const PageDev *__restrict__ pages,
-                                                     const uint32_t *__restrict__ tile_base, uint32_t n_pages,
+__global__ __launch_bounds__(256, 8) void expand_kernel(const PageDev *__restrict__ pages,
+                                                     const uint32_t *__restrict__ tile_page,
                                                      const Resume *__restrict__ resume) {
+    __shared__ __attribute__((aligned(16))) uint8_t stage[kBlocksPerTile * kWinBytes];
+
     const uint32_t tile = blockIdx.x;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
 
-    // last page whose first tile is <= tile (pages without values own no tile)
-    uint32_t lo = 0, hi = n_pages;
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (tile_base[mid] <= tile)
-            lo = mid;
-        else
-            hi = mid;
-    }
-    const PageDev pg = pages[lo];
+    const PageDev pg = pages[tile_page[tile]];
     const uint32_t n = pg.num_values;
     const uint32_t block = (tile - pg.tile_base) * kBlocksPerTile + wave;
     const uint32_t block_start = block * kBlockValues;
@@ -167,9 +163,14 @@ __global__ __launch_bounds__(256) void expand_kernel(const PageDev *__restrict__
     const uint32_t delta = (uint32_t)(pg.in_addr & 15u);
     const uint32_t end = delta + pg.in_len;
     const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(pg.in_addr - delta, (end + 3u) & ~3u);
-    auto rd = [&](uint32_t a) -> uint32_t {
-        return __builtin_amdgcn_readfirstlane(__builtin_amdgcn_raw_buffer_load_b32(rsrc, a, 0, 0));
-    };
+
+    Window win;
+    win.lo = win.hi = 0;
+    win.lds = stage + wave * kWinBytes;
+    auto rd = [&](uint32_t a) -> uint32_t { return __builtin_amdgcn_readfirstlane(win.dword(a)); };
+
+    // values of one bit-packed span that are guaranteed to fit the window together
+    const uint32_t max_vals = w ? ((kWinBytes - 64u) / w) * 8u : 0u;
 
     uint32_t *const out = (uint32_t *)pg.out_addr + block_start;
     uint32_t o = 0;  // values of this block already written
@@ -178,6 +179,8 @@ __global__ __launch_bounds__(256) void expand_kernel(const PageDev *__restrict__
             emit_rle(0u, out + o, block_n - o, lane);
             break;
         }
+        if (!win.holds(pos & ~3u, (pos & ~3u) + 24u))  // header + RLE value; normally one fill serves the block
+            win.fill(rsrc, pos, (((block_n - o) * w) >> 3) + 64u, lane);
         const uint32_t run_start = block_start + o - skip;
         const RunInfo run = decode_run(rd, pos, end, w, n - run_start);
         if (run.kind >= kEnd) {  // exhausted (or a panic path, reported by parse_kernel): zeros
@@ -185,14 +188,22 @@ __global__ __launch_bounds__(256) void expand_kernel(const PageDev *__restrict__
             break;
         }
         const uint32_t avail = run.count > skip ? run.count - skip : 0u;
-        const uint32_t take = min(avail, block_n - o);
-        if (take > 0) {
-            if (run.kind == kRle)
-                emit_rle(run.value, out + o, take, lane);
-            else
-                emit_bp_dispatch(w, rsrc, run.payload, skip, out + o, take, lane);
+        uint32_t take = min(avail, block_n - o);
+        if (run.kind == kRle) {
+            if (take > 0) emit_rle(run.value, out + o, take, lane);
+            o += take;
+        } else {
+            while (take > 0) {  // normally one pass; more only when the span's bytes exceed the window
+                const uint32_t chunk = min(take, max_vals);
+                const uint32_t b_lo = run.payload + (skip >> 3) * w;
+                const uint32_t b_hi = run.payload + ((skip + chunk + 7u) >> 3) * w + 8u;
+                if (!win.holds(b_lo & ~3u, b_hi)) win.fill(rsrc, b_lo, b_hi - b_lo + 16u, lane);
+                emit_bp_lds_dispatch(w, win.lds, span_bit0(win, run.payload, skip, w), out + o, chunk, lane);
+                o += chunk;
+                skip += chunk;
+                take -= chunk;
+            }
         }
-        o += take;
         skip = 0;
         pos = run.next;
     }
@@ -221,19 +232,19 @@ __global__ __launch_bounds__(256) void bitunpack_kernel(uint64_t in_addr, uint32
 }  // namespace pq2
 
 // ---- launchers (called from pq2_api.cpp) ----------------------------------------
-extern "C" hipError_t pq2_launch_parse(const void *pages, uint32_t n_pages, void *resume, int32_t *status,
-                                       hipStream_t stream) {
+extern "C" hipError_t pq2_launch_parse(const void *pages, uint32_t n_pages, void *resume, uint32_t *tile_page,
+                                       int32_t *status, hipStream_t stream) {
     if (n_pages == 0) return hipSuccess;
     hipLaunchKernelGGL(pq2::parse_kernel, dim3(n_pages), dim3(64), 0, stream, (const pq2::PageDev *)pages, n_pages,
-                       (pq2::Resume *)resume, status);
+                       (pq2::Resume *)resume, tile_page, status);
     return hipGetLastError();
 }
 
-extern "C" hipError_t pq2_launch_expand(const void *pages, const uint32_t *tile_base, uint32_t n_pages,
-                                        uint32_t n_tiles, const void *resume, hipStream_t stream) {
+extern "C" hipError_t pq2_launch_expand(const void *pages, const uint32_t *tile_page, uint32_t n_tiles,
+                                        const void *resume, hipStream_t stream) {
     if (n_tiles == 0) return hipSuccess;
     hipLaunchKernelGGL(pq2::expand_kernel, dim3(n_tiles), dim3(256), 0, stream, (const pq2::PageDev *)pages,
-                       tile_base, n_pages, (const pq2::Resume *)resume);
+                       tile_page, (const pq2::Resume *)resume);
     return hipGetLastError();
 }
 

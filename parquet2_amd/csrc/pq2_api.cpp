@@ -1,7 +1,7 @@
 // Host side of libpq2hip: the C ABI of include/pq2hip.h.
 //
 // A context owns, for one GPU: small device arrays for the per-batch page
-// descriptors / tile prefix / per-page status, the Resume table (8 bytes per
+// descriptors / tile prefix / per-page status, the Resume table (16 bytes per
 // 1024 output values), a pinned staging buffer for the descriptor upload and,
 // for the host-buffer entry points, device arenas and copy streams.  All of
 // them grow on demand and are reused, so a steady stream of batches performs
@@ -168,7 +168,7 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
 
     if ((st = reserve(ctx, ctx->d_meta, meta_bytes))) return st;
     if ((st = reserve(ctx, ctx->d_status, n_pages * sizeof(int32_t)))) return st;
-    if ((st = reserve(ctx, ctx->d_resume, std::max<uint64_t>(tiles, 1) * kBlocksPerTile * 8))) return st;
+    if ((st = reserve(ctx, ctx->d_resume, std::max<uint64_t>(tiles, 1) * kBlocksPerTile * 16))) return st;
     if ((st = reserve(ctx, ctx->d_tile_page, std::max<uint64_t>(tiles, 1) * sizeof(uint32_t)))) return st;
 
     PQ2_HIP(ctx, hipMemcpyAsync(ctx->d_meta.ptr, ctx->h_meta, meta_bytes, hipMemcpyHostToDevice, stream));

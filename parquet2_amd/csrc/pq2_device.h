@@ -31,13 +31,16 @@ struct PageDev {
     uint32_t tile_base;   // index of the page's first tile (tile = 4096 values)
 };
 
-// Where a 1024-value block starts inside the stream: the a-offset of the
-// header of the run that covers the block's first value (or kEndPos) and the
-// number of that run's values that precede the block.
+// Where a 1024-value block starts inside the stream: the run that covers the
+// block's first value, as far as the block needs it.  Written by parse_kernel,
+// read by expand_kernel (16 bytes per 4 KiB of output).
 struct Resume {
-    uint32_t pos;
-    uint32_t skip;
+    uint32_t next;      // a-offset of the header that follows this run (kEndPos: none, zeros follow)
+    uint32_t rem_kind;  // values of the run from the block's first value on | kind << 31
+    uint32_t payload;   // bit-packed: a-offset of the run's payload; RLE: the value
+    uint32_t skip;      // values of the run that precede the block
 };
+constexpr uint32_t kRemMask = 0x7fffffffu;
 
 enum RunKind : uint32_t { kBitpacked = 0, kRle = 1, kEnd = 2, kPanic = 3 };
 
@@ -204,23 +207,6 @@ __device__ __forceinline__ void store4(u32x4 v, uint32_t *p) {
 #endif
 }
 
-// A wave writes `count` copies of v at `out` (4-byte aligned).  Short spans go
-// out one value per lane; long ones as 16-byte-aligned dwordx4 stores (1 KiB
-// per wave instruction) with the unaligned head and tail done by a few lanes.
-__device__ __forceinline__ void emit_rle(uint32_t v, uint32_t *out, uint32_t count, uint32_t lane) {
-    if (count < 128u) {
-        for (uint32_t i = lane; i < count; i += 64u) out[i] = v;
-        return;
-    }
-    const uint32_t head = (4u - (uint32_t)(((uintptr_t)out >> 2) & 3u)) & 3u;
-    if (lane < head) out[lane] = v;
-    const uint32_t groups = (count - head) >> 2;
-    const u32x4 vv = {v, v, v, v};
-    for (uint32_t g = lane; g < groups; g += 64u) store4(vv, out + head + 4u * g);
-    const uint32_t tail = head + 4u * groups;
-    if (lane < count - tail) out[tail + lane] = v;
-}
-
 // ---- LDS-staged stream window --------------------------------------------------
 // Each wave of expand_kernel owns kWinBytes of LDS holding stream bytes
 // [lo, hi) (a-coordinates, lo 16-byte aligned).  A refill is 1..4 coalesced
@@ -253,13 +239,6 @@ struct Window {
     __device__ __forceinline__ uint32_t dword(uint32_t a) const { return *(const uint32_t *)(lds + (a - lo)); }
 };
 
-// Bit position, inside the window's LDS image, of the run-internal value
-// `v_begin`: every later value i of the span sits at span_bit0 + i * W.  The
-// caller guarantees the span's bytes are resident, so the result is < 2^16.
-__device__ __forceinline__ uint32_t span_bit0(const Window &win, uint32_t payload, uint32_t v_begin, uint32_t w) {
-    return (payload + (v_begin >> 3) * w - win.lo) * 8u + (v_begin & 7u) * w;
-}
-
 // One W-bit field at LDS bit position `bit` (LSB-first, src/encoding/bitpacked/unpack.rs:40-67).
 template <int W>
 __device__ __forceinline__ uint32_t field_at(const uint8_t *lds, uint32_t bit) {
@@ -267,73 +246,6 @@ __device__ __forceinline__ uint32_t field_at(const uint8_t *lds, uint32_t bit) {
     const uint32_t x = __builtin_amdgcn_alignbit(src[1], src[0], bit & 31u);
     constexpr uint32_t mask = W == 32 ? 0xffffffffu : ((1u << (W & 31)) - 1u);
     return x & mask;
-}
-
-// Four consecutive W-bit fields starting at LDS bit position `bit`: the lane
-// reads the aligned dwords holding its 4*W bits, funnel-shifts them down to
-// bit 0, and then every field sits at a compile-time position.
-template <int W>
-__device__ __forceinline__ u32x4 fields4_at(const uint8_t *lds, uint32_t bit) {
-    constexpr int NY = (4 * W + 31) / 32;  // dwords holding 4 fields once aligned to bit 0
-    const uint32_t *src = (const uint32_t *)(lds + ((bit >> 3) & ~3u));
-    const uint32_t s = bit & 31u;
-    uint32_t x[NY + 1];
-#pragma unroll
-    for (int i = 0; i <= NY; ++i) x[i] = src[i];
-    uint32_t y[NY];
-#pragma unroll
-    for (int i = 0; i < NY; ++i) y[i] = __builtin_amdgcn_alignbit(x[i + 1], x[i], s);
-    constexpr uint32_t mask = W == 32 ? 0xffffffffu : ((1u << (W & 31)) - 1u);
-    uint32_t o[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int lo = (i * W) >> 5;
-        const int shf = (i * W) & 31;
-        if (shf + W <= 32) {
-            o[i] = W == 32 ? y[lo] : ((y[lo] >> shf) & mask);
-        } else {
-            o[i] = __builtin_amdgcn_alignbit(y[lo + 1 < NY ? lo + 1 : lo], y[lo], shf) & mask;
-        }
-    }
-    const u32x4 res = {o[0], o[1], o[2], o[3]};
-    return res;
-}
-
-// `count` bit-packed values whose bytes are resident in the window, first one
-// at LDS bit position bit0.  Same store shapes as emit_rle.
-template <int W>
-__device__ __forceinline__ void emit_bp_lds(const uint8_t *lds, uint32_t bit0, uint32_t *out, uint32_t count,
-                                            uint32_t lane) {
-    if (count < 128u) {
-        for (uint32_t i = lane; i < count; i += 64u) out[i] = field_at<W>(lds, bit0 + i * (uint32_t)W);
-        return;
-    }
-    const uint32_t head = (4u - (uint32_t)(((uintptr_t)out >> 2) & 3u)) & 3u;
-    if (lane < head) out[lane] = field_at<W>(lds, bit0 + lane * (uint32_t)W);
-    const uint32_t groups = (count - head) >> 2;
-    const uint32_t body0 = bit0 + head * (uint32_t)W;
-    for (uint32_t g = lane; g < groups; g += 64u)
-        store4(fields4_at<W>(lds, body0 + g * (4u * (uint32_t)W)), out + head + 4u * g);
-    const uint32_t tail = head + 4u * groups;
-    if (lane < count - tail) out[tail + lane] = field_at<W>(lds, bit0 + (tail + lane) * (uint32_t)W);
-}
-
-// Width dispatch: one specialised body per bit width 1..32.
-__device__ __forceinline__ void emit_bp_lds_dispatch(uint32_t w, const uint8_t *lds, uint32_t bit0, uint32_t *out,
-                                                     uint32_t count, uint32_t lane) {
-    switch (w) {
-#define PQ2_W(N)                                       \
-    case N:                                            \
-        emit_bp_lds<N>(lds, bit0, out, count, lane);   \
-        break;
-        PQ2_W(1) PQ2_W(2) PQ2_W(3) PQ2_W(4) PQ2_W(5) PQ2_W(6) PQ2_W(7) PQ2_W(8)
-        PQ2_W(9) PQ2_W(10) PQ2_W(11) PQ2_W(12) PQ2_W(13) PQ2_W(14) PQ2_W(15) PQ2_W(16)
-        PQ2_W(17) PQ2_W(18) PQ2_W(19) PQ2_W(20) PQ2_W(21) PQ2_W(22) PQ2_W(23) PQ2_W(24)
-        PQ2_W(25) PQ2_W(26) PQ2_W(27) PQ2_W(28) PQ2_W(29) PQ2_W(30) PQ2_W(31) PQ2_W(32)
-#undef PQ2_W
-        default:
-            break;
-    }
 }
 
 // ---- direct-from-memory extraction (bitunpack_kernel: no headers, no staging) -------------

@@ -5,15 +5,19 @@
 //   parse_kernel   one wave per page.  Walks the run headers (a serial chain:
 //                  the position of a header is only known once the previous
 //                  one is decoded) with the stream staged through an LDS ring,
-//                  and records, for every 1024-value block of the output,
-//                  where in the stream that block starts (Resume).  8 bytes are
-//                  written per 4 KiB of output; no run table is materialised.
+//                  and records, for every 1024-value block of the output, the
+//                  run that covers the block's first value (Resume, 16 bytes
+//                  per 4 KiB of output).  No run table is materialised.
 //   expand_kernel  one wave per 1024-value block, four blocks per workgroup.
-//                  Re-decodes the (few) headers that cover its block, starting
-//                  from the Resume entry, and writes the values: RLE runs as
-//                  splat dwordx4 stores, bit-packed runs through the
-//                  per-width extract4<W> bodies.  All HBM traffic of the decode
-//                  (payload reads, value stores) happens here.
+//                  Stages the block's stream bytes in LDS with one coalesced
+//                  fill, walks the few headers that cover the block into a
+//                  64-entry run table (one run per lane), and then every lane
+//                  produces 4 consecutive values per step: it finds its run by
+//                  binary search in the table, takes RLE values as they are and
+//                  bit-packed fields out of the LDS image, and writes one
+//                  16-byte-aligned dwordx4 -- 1 KiB of contiguous output per
+//                  wave instruction, whatever the run boundaries are.  All HBM
+//                  traffic of the decode happens here.
 //
 // bitunpack_kernel is the header-less special case (bitpacked::Decoder<u32>).
 #include "pq2_device.h"
@@ -45,19 +49,20 @@ __global__ __launch_bounds__(64) void parse_kernel(const PageDev *__restrict__ p
     const uint32_t n_blocks = (n + kBlockValues - 1) / kBlockValues;
     Resume *const entries = resume + (size_t)pg.tile_base * kBlocksPerTile;
     // expand_kernel finds its page through tile_page[tile]
-    for (uint32_t t = lane; t < (n_blocks + kBlocksPerTile - 1) / kBlocksPerTile; t += 64) tile_page[pg.tile_base + t] = page;
+    for (uint32_t t = lane; t < (n_blocks + kBlocksPerTile - 1) / kBlocksPerTile; t += 64)
+        tile_page[pg.tile_base + t] = page;
 
-    // fills entries [from, n_blocks) with "stream exhausted"
+    // entries [from, n_blocks): the stream is exhausted, zeros follow (mod.rs:95)
     auto fill_end = [&](uint32_t from) {
-        for (uint32_t b = from + lane; b < n_blocks; b += 64) {
-            Resume e;
-            e.pos = kEndPos;
-            e.skip = 0;
-            entries[b] = e;
-        }
+        Resume e;
+        e.next = kEndPos;
+        e.rem_kind = kRemMask | (kRle << 31);
+        e.payload = 0;
+        e.skip = 0;
+        for (uint32_t b = from + lane; b < n_blocks; b += 64) entries[b] = e;
     };
 
-    if (w == 0 || pg.in_len == 0 || w > 32) {  // decoder.rs:31-37: nothing to iterate; mod.rs:95 pads with zeros
+    if (w == 0 || pg.in_len == 0 || w > 32) {  // decoder.rs:31-37: nothing to iterate
         fill_end(0);
         if (lane == 0) status[page] = 0;
         return;
@@ -121,13 +126,18 @@ __global__ __launch_bounds__(64) void parse_kernel(const PageDev *__restrict__ p
         }
         if (run.count > 0) {
             const uint32_t last_block = (produced + run.count - 1) / kBlockValues;
-            for (uint32_t b = next_block + lane; b <= last_block; b += 64) {
-                Resume e;
-                e.pos = pos;
-                e.skip = b * kBlockValues - produced;
-                entries[b] = e;
+            if (last_block >= next_block) {
+                for (uint32_t b = next_block + lane; b <= last_block; b += 64) {
+                    const uint32_t skip = b * kBlockValues - produced;
+                    Resume e;
+                    e.next = run.next;
+                    e.rem_kind = (run.count - skip) | (run.kind << 31);
+                    e.payload = run.kind == kRle ? run.value : run.payload;
+                    e.skip = skip;
+                    entries[b] = e;
+                }
+                next_block = last_block + 1;
             }
-            next_block = last_block + 1;
         }
         produced += run.count;
         pos = run.next;
@@ -139,10 +149,126 @@ __global__ __launch_bounds__(64) void parse_kernel(const PageDev *__restrict__ p
 // ---------------------------------------------------------------------------
 // expand_kernel
 // ---------------------------------------------------------------------------
+constexpr uint32_t kTableRuns = 64;      // run-table entries per wave (the last one stays a sentinel)
+constexpr uint32_t kNoRun = 0xffffffffu; // table key of an unused entry: compares greater than any position
+
+// One wave decodes block [block_start, block_start + block_n) of a page whose
+// width is W.  `tbl` (kTableRuns * 8 bytes) and `win` are the wave's LDS.
+template <int W>
+__device__ __forceinline__ void expand_block(const __amdgpu_buffer_rsrc_t rsrc, Window &win, uint2 *tbl,
+                                             const Resume rs, const uint32_t end, const uint32_t n,
+                                             const uint32_t block_start, const uint32_t block_n, uint32_t *out,
+                                             const uint32_t lane) {
+    constexpr uint32_t w = (uint32_t)W;
+    constexpr uint32_t kMaxVals = ((kWinBytes - 64u) / w) * 8u;  // values of one span that surely fit the window
+    auto rd = [&](uint32_t a) -> uint32_t { return __builtin_amdgcn_readfirstlane(win.dword(a)); };
+
+    // the run being consumed
+    uint32_t kind = rs.rem_kind >> 31;
+    uint32_t rem = rs.rem_kind & kRemMask;
+    uint32_t payload = rs.payload;  // RLE: the value
+    uint32_t skip = rs.skip;
+    uint32_t next = rs.next;
+
+    const uint32_t mis = (uint32_t)(((uintptr_t)out >> 2) & 3u);  // values between the 16-byte grid and `out`
+    uint32_t lo = 0;                                               // block positions [0, lo) are written
+
+    while (lo < block_n) {
+        // ---- phase 1: runs covering [lo, hi) into the table, lane r <- run r ----------------------
+        uint32_t key = kNoRun, info = 0;  // this lane's entry: (start << 1 | kind), value or LDS bit position
+        uint32_t nruns = 0, o = lo;
+        while (o < block_n && nruns < kTableRuns - 1) {
+            if (rem == 0) {  // next run
+                if (next == kEndPos) {
+                    kind = kRle, rem = kRemMask, payload = 0;
+                    continue;
+                }
+                if (!win.holds(next & ~3u, (next & ~3u) + 24u)) {
+                    if (nruns) break;  // the table's runs still need the resident bytes: finish this pass first
+                    win.fill(rsrc, next, (((block_n - o) * w) >> 3) + 64u, lane);
+                }
+                const RunInfo run = decode_run(rd, next, end, w, n - (block_start + o));
+                if (run.kind >= kEnd) {  // exhausted (or a panic path, reported by parse_kernel): zeros
+                    next = kEndPos;
+                    continue;
+                }
+                kind = run.kind, rem = run.count, skip = 0, next = run.next;
+                payload = run.kind == kRle ? run.value : run.payload;
+                continue;
+            }
+            uint32_t take = min(rem, block_n - o);
+            uint32_t value = payload;
+            if (kind == kBitpacked) {
+                const uint32_t b_lo = payload + (skip >> 3) * w;  // first byte of the group holding value `skip`
+                uint32_t b_hi = payload + ((skip + take + 7u) >> 3) * w + 8u;
+                if (!win.holds(b_lo & ~3u, b_hi)) {
+                    if (nruns) break;
+                    take = min(take, kMaxVals);
+                    b_hi = payload + ((skip + take + 7u) >> 3) * w + 8u;
+                    // stage what the rest of the block is expected to need, not just this span
+                    win.fill(rsrc, b_lo, max(b_hi - b_lo + 16u, (((block_n - o) * w) >> 3) + 64u), lane);
+                }
+                value = (b_lo - win.lo) * 8u + (skip & 7u) * w;  // LDS bit position of the run's value `skip`
+            }
+            if (lane == nruns) {
+                key = (o << 1) | kind;
+                info = value;
+            }
+            ++nruns;
+            o += take;
+            rem -= take;
+            skip += take;
+        }
+        const uint32_t hi = o;  // this pass writes block positions [lo, hi)
+        tbl[lane] = make_uint2(key, info);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- phase 2: every lane produces 4 consecutive values per step ---------------------------------
+        // chunk q holds block positions [4q - mis, 4q - mis + 4): its address is 16-byte aligned
+        const uint32_t q_end = (hi + mis + 3u) >> 2;
+        for (uint32_t q = ((lo + mis) >> 2) + lane; q < q_end; q += 64u) {
+            const int32_t p = (int32_t)(q * 4u) - (int32_t)mis;
+            const uint32_t p0 = (uint32_t)max(p, (int32_t)lo);
+            // last table entry whose start is <= p0 (entry 0 starts at lo; unused entries compare greater)
+            const uint32_t probe = (p0 << 1) | 1u;
+            uint32_t j = 0;
+#pragma unroll
+            for (uint32_t step = kTableRuns / 2; step > 0; step >>= 1)
+                if (tbl[j + step].x <= probe) j += step;
+            uint2 cur = tbl[j];
+            uint32_t nxt = tbl[j + 1].x;
+            uint32_t v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t pk = (uint32_t)max(p + k, (int32_t)p0);
+                if (((pk << 1) | 1u) >= nxt) {  // runs hold at least one value: one step forward is enough
+                    ++j;
+                    cur = tbl[j];
+                    nxt = tbl[j + 1].x;
+                }
+                const uint32_t bit = cur.y + (pk - (cur.x >> 1)) * w;
+                const uint32_t f = field_at<W>(win.lds, bit & (kWinBytes * 8u - 1u));
+                v[k] = (cur.x & 1u) ? cur.y : f;
+            }
+            if (p >= (int32_t)lo && p + 4 <= (int32_t)hi) {
+                const u32x4 vv = {v[0], v[1], v[2], v[3]};
+                store4(vv, out + p);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (p + k >= (int32_t)lo && p + k < (int32_t)hi) out[p + k] = v[k];
+            }
+        }
+        lo = hi;
+    }
+}
+
 __global__ __launch_bounds__(256, 8) void expand_kernel(const PageDev *__restrict__ pages,
-                                                     const uint32_t *__restrict__ tile_page,
-                                                     const Resume *__restrict__ resume) {
+                                                       const uint32_t *__restrict__ tile_page,
+                                                       const Resume *__restrict__ resume) {
     __shared__ __attribute__((aligned(16))) uint8_t stage[kBlocksPerTile * kWinBytes];
+    __shared__ __attribute__((aligned(16))) uint2 table[kBlocksPerTile * (kTableRuns + 2)];
 
     const uint32_t tile = blockIdx.x;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -154,11 +280,12 @@ __global__ __launch_bounds__(256, 8) void expand_kernel(const PageDev *__restric
     const uint32_t block_start = block * kBlockValues;
     if (block_start >= n) return;
     const uint32_t block_n = min(kBlockValues, n - block_start);
-    const uint32_t w = pg.num_bits;
 
-    const Resume rs = resume[(size_t)tile * kBlocksPerTile + wave];
-    uint32_t pos = __builtin_amdgcn_readfirstlane(rs.pos);
-    uint32_t skip = __builtin_amdgcn_readfirstlane(rs.skip);
+    Resume rs = resume[(size_t)tile * kBlocksPerTile + wave];
+    rs.next = __builtin_amdgcn_readfirstlane(rs.next);
+    rs.rem_kind = __builtin_amdgcn_readfirstlane(rs.rem_kind);
+    rs.payload = __builtin_amdgcn_readfirstlane(rs.payload);
+    rs.skip = __builtin_amdgcn_readfirstlane(rs.skip);
 
     const uint32_t delta = (uint32_t)(pg.in_addr & 15u);
     const uint32_t end = delta + pg.in_len;
@@ -167,45 +294,30 @@ __global__ __launch_bounds__(256, 8) void expand_kernel(const PageDev *__restric
     Window win;
     win.lo = win.hi = 0;
     win.lds = stage + wave * kWinBytes;
-    auto rd = [&](uint32_t a) -> uint32_t { return __builtin_amdgcn_readfirstlane(win.dword(a)); };
-
-    // values of one bit-packed span that are guaranteed to fit the window together
-    const uint32_t max_vals = w ? ((kWinBytes - 64u) / w) * 8u : 0u;
-
+    uint2 *tbl = table + wave * (kTableRuns + 2);
+    if (lane < 2) tbl[kTableRuns + lane] = make_uint2(kNoRun, 0u);  // read by tbl[j + 1] only
     uint32_t *const out = (uint32_t *)pg.out_addr + block_start;
-    uint32_t o = 0;  // values of this block already written
-    while (o < block_n) {
-        if (pos == kEndPos) {
-            emit_rle(0u, out + o, block_n - o, lane);
+
+    switch (pg.num_bits) {
+#define PQ2_W(N)                                                                             \
+    case N:                                                                                  \
+        expand_block<N>(rsrc, win, tbl, rs, end, n, block_start, block_n, out, lane);        \
+        break;
+        PQ2_W(1) PQ2_W(2) PQ2_W(3) PQ2_W(4) PQ2_W(5) PQ2_W(6) PQ2_W(7) PQ2_W(8)
+        PQ2_W(9) PQ2_W(10) PQ2_W(11) PQ2_W(12) PQ2_W(13) PQ2_W(14) PQ2_W(15) PQ2_W(16)
+        PQ2_W(17) PQ2_W(18) PQ2_W(19) PQ2_W(20) PQ2_W(21) PQ2_W(22) PQ2_W(23) PQ2_W(24)
+        PQ2_W(25) PQ2_W(26) PQ2_W(27) PQ2_W(28) PQ2_W(29) PQ2_W(30) PQ2_W(31) PQ2_W(32)
+#undef PQ2_W
+        default: {  // width 0 (or a skipped page): zeros
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            const uint32_t head = min((4u - (uint32_t)(((uintptr_t)out >> 2) & 3u)) & 3u, block_n);
+            if (lane < head) out[lane] = 0u;
+            const uint32_t groups = (block_n - head) >> 2;
+            for (uint32_t g = lane; g < groups; g += 64u) store4(z, out + head + 4u * g);
+            const uint32_t tail = head + 4u * groups;
+            if (lane < block_n - tail) out[tail + lane] = 0u;
             break;
         }
-        if (!win.holds(pos & ~3u, (pos & ~3u) + 24u))  // header + RLE value; normally one fill serves the block
-            win.fill(rsrc, pos, (((block_n - o) * w) >> 3) + 64u, lane);
-        const uint32_t run_start = block_start + o - skip;
-        const RunInfo run = decode_run(rd, pos, end, w, n - run_start);
-        if (run.kind >= kEnd) {  // exhausted (or a panic path, reported by parse_kernel): zeros
-            emit_rle(0u, out + o, block_n - o, lane);
-            break;
-        }
-        const uint32_t avail = run.count > skip ? run.count - skip : 0u;
-        uint32_t take = min(avail, block_n - o);
-        if (run.kind == kRle) {
-            if (take > 0) emit_rle(run.value, out + o, take, lane);
-            o += take;
-        } else {
-            while (take > 0) {  // normally one pass; more only when the span's bytes exceed the window
-                const uint32_t chunk = min(take, max_vals);
-                const uint32_t b_lo = run.payload + (skip >> 3) * w;
-                const uint32_t b_hi = run.payload + ((skip + chunk + 7u) >> 3) * w + 8u;
-                if (!win.holds(b_lo & ~3u, b_hi)) win.fill(rsrc, b_lo, b_hi - b_lo + 16u, lane);
-                emit_bp_lds_dispatch(w, win.lds, span_bit0(win, run.payload, skip, w), out + o, chunk, lane);
-                o += chunk;
-                skip += chunk;
-                take -= chunk;
-            }
-        }
-        skip = 0;
-        pos = run.next;
     }
 }
 

@@ -12,7 +12,7 @@ import numpy as np
 from .error import DeviceError, raise_for_status
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "lib", "libpq2hip.so")
+LIB_PATH = os.environ.get("PQ2_LIB") or os.path.join(PKG, "lib", "libpq2hip.so")  # PQ2_LIB: A/B builds
 
 OK, OUT_OF_SPEC, INVALID_PARAMETER, FEATURE_NOT_SUPPORTED, WOULD_OVER_ALLOCATE, REFERENCE_WOULD_PANIC, DEVICE_ERROR = \
     range(7)

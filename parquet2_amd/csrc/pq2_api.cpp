@@ -18,10 +18,10 @@
 #include "../../include/pq2hip.h"
 
 extern "C" {
-hipError_t pq2_launch_parse(const void *pages, uint32_t n_pages, void *resume, uint32_t *tile_page, int32_t *status,
-                            hipStream_t stream);
+hipError_t pq2_launch_parse(const void *pages, uint32_t n_pages, void *resume, uint32_t *tile_page, uint32_t *run_pos,
+                            int32_t *status, hipStream_t stream);
 hipError_t pq2_launch_expand(const void *pages, const uint32_t *tile_page, uint32_t n_tiles, const void *resume,
-                             hipStream_t stream);
+                             const uint32_t *run_pos, hipStream_t stream);
 hipError_t pq2_launch_bitunpack(const void *d_packed, uint32_t packed_len, uint32_t num_bits, uint32_t length,
                                 uint32_t *d_out, hipStream_t stream);
 }
@@ -34,12 +34,13 @@ constexpr uint32_t kBlocksPerTile = 4;
 struct PageDev {  // must match pq2::PageDev
     uint64_t in_addr;
     uint64_t out_addr;
+    uint64_t run_base;
     uint32_t in_len;
     uint32_t num_values;
     uint32_t num_bits;
     uint32_t tile_base;
 };
-static_assert(sizeof(PageDev) == 32, "PageDev layout");
+static_assert(sizeof(PageDev) == 40, "PageDev layout");
 
 struct DevBuf {
     void *ptr = nullptr;
@@ -56,7 +57,7 @@ struct pq2_ctx {
     size_t h_meta_cap = 0;
     hipEvent_t meta_copied = nullptr;  // the previous upload has left h_meta
     bool meta_in_flight = false;
-    DevBuf d_meta, d_status, d_resume, d_tile_page;
+    DevBuf d_meta, d_status, d_resume, d_tile_page, d_run_pos;
     std::vector<int32_t> host_status;  // statuses decided on the host (bad num_bits)
     uint64_t last_n_pages = 0;
     hipStream_t last_stream = nullptr;
@@ -141,7 +142,7 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
     }
     PageDev *pages = static_cast<PageDev *>(ctx->h_meta);
 
-    uint64_t tiles = 0;
+    uint64_t tiles = 0, run_entries = 0;
     for (uint64_t i = 0; i < n_pages; ++i) {
         const pq2_page_desc &d = descs[i];
         if (d.in_len > PQ2_MAX_PAGE_BYTES) return fail(ctx, PQ2_INVALID_PARAMETER, "page stream too long");
@@ -161,6 +162,10 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
             p.num_values = 0;
         }
         p.tile_base = static_cast<uint32_t>(tiles);
+        // header-position list: a run that yields values takes >= 2 stream bytes and >= 1 value; + the closing
+        // entry, + the 64 entries a wave may read past the last one, rounded to whole 64-entry stores
+        p.run_base = run_entries;
+        run_entries += (std::min<uint64_t>(p.num_values, d.in_len / 2) + 1 + 64 + 63) & ~uint64_t(63);
         tiles += (p.num_values + kTileValues - 1) / kTileValues;
         if (tiles > 0x7fffffffull) return fail(ctx, PQ2_INVALID_PARAMETER, "batch too large for one launch");
     }
@@ -170,6 +175,7 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
     if ((st = reserve(ctx, ctx->d_status, n_pages * sizeof(int32_t)))) return st;
     if ((st = reserve(ctx, ctx->d_resume, std::max<uint64_t>(tiles, 1) * kBlocksPerTile * 16))) return st;
     if ((st = reserve(ctx, ctx->d_tile_page, std::max<uint64_t>(tiles, 1) * sizeof(uint32_t)))) return st;
+    if ((st = reserve(ctx, ctx->d_run_pos, std::max<uint64_t>(run_entries, 1) * sizeof(uint32_t)))) return st;
 
     PQ2_HIP(ctx, hipMemcpyAsync(ctx->d_meta.ptr, ctx->h_meta, meta_bytes, hipMemcpyHostToDevice, stream));
     PQ2_HIP(ctx, hipEventRecord(ctx->meta_copied, stream));
@@ -182,10 +188,12 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
         for (auto &e : stamp.e) PQ2_HIP(ctx, hipEventCreate(&e));
         PQ2_HIP(ctx, hipEventRecord(stamp.e[0], stream));
     }
-    PQ2_HIP(ctx, pq2_launch_parse(d_pages, static_cast<uint32_t>(n_pages), ctx->d_resume.ptr, d_tile_page,
+    uint32_t *d_run_pos = static_cast<uint32_t *>(ctx->d_run_pos.ptr);
+    PQ2_HIP(ctx, pq2_launch_parse(d_pages, static_cast<uint32_t>(n_pages), ctx->d_resume.ptr, d_tile_page, d_run_pos,
                                   static_cast<int32_t *>(ctx->d_status.ptr), stream));
     if (ctx->profiling) PQ2_HIP(ctx, hipEventRecord(stamp.e[1], stream));
-    PQ2_HIP(ctx, pq2_launch_expand(d_pages, d_tile_page, static_cast<uint32_t>(tiles), ctx->d_resume.ptr, stream));
+    PQ2_HIP(ctx, pq2_launch_expand(d_pages, d_tile_page, static_cast<uint32_t>(tiles), ctx->d_resume.ptr, d_run_pos,
+                                   stream));
     if (ctx->profiling) {
         PQ2_HIP(ctx, hipEventRecord(stamp.e[2], stream));
         ctx->stamps.push_back(stamp);
@@ -230,7 +238,8 @@ int32_t pq2_ctx_destroy(pq2_ctx *ctx) {
     if (!ctx) return PQ2_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    for (DevBuf *b : {&ctx->d_meta, &ctx->d_status, &ctx->d_resume, &ctx->d_tile_page, &ctx->d_in, &ctx->d_out})
+    for (DevBuf *b : {&ctx->d_meta, &ctx->d_status, &ctx->d_resume, &ctx->d_tile_page, &ctx->d_run_pos, &ctx->d_in,
+                      &ctx->d_out})
         if (b->ptr) (void)hipFree(b->ptr);
     if (ctx->h_meta) (void)hipHostFree(ctx->h_meta);
     if (ctx->meta_copied) (void)hipEventDestroy(ctx->meta_copied);

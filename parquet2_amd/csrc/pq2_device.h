@@ -21,24 +21,31 @@ constexpr uint32_t kBlocksPerTile = 4;     // one 256-thread workgroup = 4 wave-
 constexpr uint32_t kTileValues = kBlockValues * kBlocksPerTile;
 constexpr uint32_t kEndPos = 0xffffffffu;  // resume position meaning "stream exhausted: zeros"
 
-// Device-side page descriptor (32 bytes), built by the host from pq2_page_desc.
+// Device-side page descriptor (40 bytes), built by the host from pq2_page_desc.
 struct PageDev {
     uint64_t in_addr;     // device address of the first stream byte
     uint64_t out_addr;    // device address of the page's first output value
+    uint64_t run_base;    // index of the page's first entry in the header-position list
     uint32_t in_len;      // stream bytes
     uint32_t num_values;  // values to produce (0 if the page is skipped)
     uint32_t num_bits;    // 0..32
     uint32_t tile_base;   // index of the page's first tile (tile = 4096 values)
 };
 
+// The header-position list: for every page, the a-offsets of the headers of
+// its runs that yield at least one value, in stream order, closed by kEndPos.
+// parse_kernel writes it (4 bytes per run); expand_kernel reads the entries of
+// the runs that start inside its block, one per lane, and decodes those
+// headers in parallel.
+//
 // Where a 1024-value block starts inside the stream: the run that covers the
 // block's first value, as far as the block needs it.  Written by parse_kernel,
 // read by expand_kernel (16 bytes per 4 KiB of output).
 struct Resume {
-    uint32_t next;      // a-offset of the header that follows this run (kEndPos: none, zeros follow)
-    uint32_t rem_kind;  // values of the run from the block's first value on | kind << 31
-    uint32_t payload;   // bit-packed: a-offset of the run's payload; RLE: the value
-    uint32_t skip;      // values of the run that precede the block
+    uint32_t run_index;  // index of this run in the page's header-position list
+    uint32_t rem_kind;   // values of the run from the block's first value on | kind << 31
+    uint32_t payload;    // bit-packed: a-offset of the run's payload; RLE: the value
+    uint32_t skip;       // values of the run that precede the block
 };
 constexpr uint32_t kRemMask = 0x7fffffffu;
 
@@ -195,6 +202,87 @@ __device__ __forceinline__ RunInfo decode_run(Rd rd, uint32_t pos, uint32_t end,
         r.next = p + rb;
     }
     return r;
+}
+
+// One lane's view of a run: what expand_kernel needs to place and produce its values.
+struct LaneRun {
+    uint32_t kind;   // kBitpacked | kRle
+    uint32_t count;  // values the run yields before any clamp to the page length (saturated at 2^31 - 1)
+    uint32_t info;   // bit-packed: a-offset of the payload; RLE: the value
+};
+
+// Per-lane header decode out of an LDS image: `lds + off` is the header's first
+// byte and at least 24 bytes from off & ~3 are readable.  Same arithmetic as
+// decode_run, for a header parse_kernel has already accepted (it lies inside
+// the stream and its run yields values), so no end-of-stream case remains but
+// the clamp of a bit-packed payload cut by the end of the stream.
+template <int W>
+__device__ __forceinline__ LaneRun decode_lane(const uint8_t *lds, uint32_t off, uint32_t hp, uint32_t end) {
+    constexpr uint32_t w = (uint32_t)W;
+    const uint32_t *src = (const uint32_t *)(lds + (off & ~3u));
+    const uint32_t sh = (off & 3u) * 8u;
+    const uint32_t d0 = src[0], d1 = src[1], d2 = src[2];
+    const uint32_t x0 = __builtin_amdgcn_alignbit(d1, d0, sh);
+    const uint32_t x1 = __builtin_amdgcn_alignbit(d2, d1, sh);
+    uint64_t ind;
+    uint32_t c, rest;
+    if ((x0 & 0x80u) == 0) {
+        ind = x0 & 0x7fu;
+        c = 1;
+        rest = __builtin_amdgcn_alignbit(x1, x0, 8);
+    } else if ((x0 & 0x8000u) == 0) {
+        ind = (x0 & 0x7fu) | ((x0 >> 1) & 0x3f80u);
+        c = 2;
+        rest = __builtin_amdgcn_alignbit(x1, x0, 16);
+    } else {  // 3..10 header bytes
+        const uint32_t d3 = src[3], d4 = src[4];
+        const uint32_t x2 = __builtin_amdgcn_alignbit(d3, d2, sh);
+        const uint32_t x3 = __builtin_amdgcn_alignbit(d4, d3, sh);
+        ind = 0;
+        c = 0;
+        bool done = false;
+        for (uint32_t i = 0; i < 10 && !done; ++i) {
+            const uint32_t word = i < 4 ? x0 : (i < 8 ? x1 : x2);
+            const uint32_t b = (word >> ((i & 3u) * 8u)) & 0xffu;
+            c = i + 1;
+            ind |= (uint64_t)(b & 0x7fu) << (7u * i);
+            done = (b & 0x80u) == 0;
+        }
+        // the 4 bytes that follow a header of c = 3..10 bytes
+        const uint32_t lo_w = c < 4 ? x0 : (c < 8 ? x1 : x2);
+        const uint32_t hi_w = c < 4 ? x1 : (c < 8 ? x2 : x3);
+        rest = __builtin_amdgcn_alignbit(hi_w, lo_w, (c & 3u) * 8u);
+    }
+    LaneRun r;
+    const uint32_t p = hp + c;
+    const uint64_t n = ind >> 1;
+    if (ind & 1u) {
+        const uint32_t left = end - p;
+        uint64_t k;
+        if (n > 0x0fffffffull || n * w > left)  // decoder.rs:51: only whole values inside the remaining bytes
+            k = (uint64_t)(left / w) * 8u + ((left % w) * 8u) / w;
+        else
+            k = n * 8u;
+        r.kind = kBitpacked;
+        r.count = k < 0x7fffffffull ? (uint32_t)k : 0x7fffffffu;
+        r.info = p;
+    } else {
+        constexpr uint32_t rb = (w + 7u) >> 3;
+        r.kind = kRle;
+        r.count = n < 0x7fffffffull ? (uint32_t)n : 0x7fffffffu;
+        r.info = rb < 4 ? (rest & ((1u << ((rb & 3u) * 8u)) - 1u)) : rest;
+    }
+    return r;
+}
+
+// Inclusive prefix sum over the 64 lanes of a wave.
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v, uint32_t lane) {
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
 }
 
 // ---- stores -------------------------------------------------------------------

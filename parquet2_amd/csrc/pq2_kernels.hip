@@ -4,20 +4,23 @@
 //
 //   parse_kernel   one wave per page.  Walks the run headers (a serial chain:
 //                  the position of a header is only known once the previous
-//                  one is decoded) with the stream staged through an LDS ring,
-//                  and records, for every 1024-value block of the output, the
-//                  run that covers the block's first value (Resume, 16 bytes
-//                  per 4 KiB of output).  No run table is materialised.
+//                  one is decoded) with the stream staged through an LDS ring.
+//                  It writes the position of every header (4 bytes per run)
+//                  and, for every 1024-value block of the output, the run that
+//                  covers the block's first value (Resume, 16 bytes per 4 KiB
+//                  of output).  It reads the stream once and writes no values.
 //   expand_kernel  one wave per 1024-value block, four blocks per workgroup.
 //                  Stages the block's stream bytes in LDS with one coalesced
-//                  fill, walks the few headers that cover the block into a
-//                  64-entry run table (one run per lane), and then every lane
-//                  produces 4 consecutive values per step: it finds its run by
-//                  binary search in the table, takes RLE values as they are and
-//                  bit-packed fields out of the LDS image, and writes one
-//                  16-byte-aligned dwordx4 -- 1 KiB of contiguous output per
-//                  wave instruction, whatever the run boundaries are.  All HBM
-//                  traffic of the decode happens here.
+//                  fill; loads the positions of the headers that follow the
+//                  block's first run, one per lane, and decodes those headers
+//                  in parallel; a wave-wide prefix sum of the run lengths gives
+//                  every run its output offset and fills a 64-entry run table.
+//                  Then every lane produces 4 consecutive values per step: it
+//                  finds its run by binary search in the table, takes RLE
+//                  values as they are and bit-packed fields out of the LDS
+//                  image, and writes one 16-byte-aligned dwordx4 -- 1 KiB of
+//                  contiguous output per wave instruction, whatever the run
+//                  boundaries are.  All value traffic of the decode is here.
 //
 // bitunpack_kernel is the header-less special case (bitpacked::Decoder<u32>).
 #include "pq2_device.h"
@@ -32,7 +35,7 @@ constexpr uint32_t kRing = 2 * kHalf;
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void parse_kernel(const PageDev *__restrict__ pages, uint32_t n_pages,
                                                    Resume *__restrict__ resume, uint32_t *__restrict__ tile_page,
-                                                   int32_t *__restrict__ status) {
+                                                   uint32_t *__restrict__ run_pos, int32_t *__restrict__ status) {
     // ring[a & (kRing-1)] holds stream byte a for a in [win_lo, win_lo + kRing)
     __shared__ __attribute__((aligned(16))) uint8_t ring[kRing];
 
@@ -52,14 +55,20 @@ __global__ __launch_bounds__(64) void parse_kernel(const PageDev *__restrict__ p
     for (uint32_t t = lane; t < (n_blocks + kBlocksPerTile - 1) / kBlocksPerTile; t += 64)
         tile_page[pg.tile_base + t] = page;
 
-    // entries [from, n_blocks): the stream is exhausted, zeros follow (mod.rs:95)
+    uint32_t *const hdrs = run_pos + pg.run_base;  // header positions of the runs that yield values
+    uint32_t n_runs = 0;                           // entries of `hdrs` produced so far
+    uint32_t pend = 0;                             // lane i holds entry (n_runs & ~63) + i until 64 are complete
+
+    // entries [from, n_blocks): the stream is exhausted, zeros follow (mod.rs:95); closes the header list
     auto fill_end = [&](uint32_t from) {
         Resume e;
-        e.next = kEndPos;
+        e.run_index = n_runs;
         e.rem_kind = kRemMask | (kRle << 31);
         e.payload = 0;
         e.skip = 0;
         for (uint32_t b = from + lane; b < n_blocks; b += 64) entries[b] = e;
+        if (lane == (n_runs & 63u)) pend = kEndPos;
+        if (lane <= (n_runs & 63u)) hdrs[(n_runs & ~63u) + lane] = pend;
     };
 
     if (w == 0 || pg.in_len == 0 || w > 32) {  // decoder.rs:31-37: nothing to iterate
@@ -125,12 +134,14 @@ __global__ __launch_bounds__(64) void parse_kernel(const PageDev *__restrict__ p
             break;
         }
         if (run.count > 0) {
+            if (lane == (n_runs & 63u)) pend = pos;
+            if ((n_runs & 63u) == 63u) hdrs[(n_runs & ~63u) + lane] = pend;  // 64 positions, one coalesced store
             const uint32_t last_block = (produced + run.count - 1) / kBlockValues;
             if (last_block >= next_block) {
                 for (uint32_t b = next_block + lane; b <= last_block; b += 64) {
                     const uint32_t skip = b * kBlockValues - produced;
                     Resume e;
-                    e.next = run.next;
+                    e.run_index = n_runs;
                     e.rem_kind = (run.count - skip) | (run.kind << 31);
                     e.payload = run.kind == kRle ? run.value : run.payload;
                     e.skip = skip;
@@ -138,6 +149,7 @@ __global__ __launch_bounds__(64) void parse_kernel(const PageDev *__restrict__ p
                 }
                 next_block = last_block + 1;
             }
+            ++n_runs;
         }
         produced += run.count;
         pos = run.next;
@@ -153,74 +165,79 @@ constexpr uint32_t kTableRuns = 64;      // run-table entries per wave (the last
 constexpr uint32_t kNoRun = 0xffffffffu; // table key of an unused entry: compares greater than any position
 
 // One wave decodes block [block_start, block_start + block_n) of a page whose
-// width is W.  `tbl` (kTableRuns * 8 bytes) and `win` are the wave's LDS.
+// width is W.  `tbl` (kTableRuns + 2 entries) and `win` are the wave's LDS.
 template <int W>
 __device__ __forceinline__ void expand_block(const __amdgpu_buffer_rsrc_t rsrc, Window &win, uint2 *tbl,
-                                             const Resume rs, const uint32_t end, const uint32_t n,
-                                             const uint32_t block_start, const uint32_t block_n, uint32_t *out,
-                                             const uint32_t lane) {
+                                             const Resume rs, const uint32_t *__restrict__ hdrs,
+                                             const uint32_t end, const uint32_t n, const uint32_t block_start,
+                                             const uint32_t block_n, uint32_t *out, const uint32_t lane) {
     constexpr uint32_t w = (uint32_t)W;
     constexpr uint32_t kMaxVals = ((kWinBytes - 64u) / w) * 8u;  // values of one span that surely fit the window
-    auto rd = [&](uint32_t a) -> uint32_t { return __builtin_amdgcn_readfirstlane(win.dword(a)); };
+    constexpr uint32_t kLaneRuns = kTableRuns - 1;               // runs decoded by lanes in one pass
 
-    // the run being consumed
+    // the first run of the pass (wave-uniform)
     uint32_t kind = rs.rem_kind >> 31;
     uint32_t rem = rs.rem_kind & kRemMask;
     uint32_t payload = rs.payload;  // RLE: the value
     uint32_t skip = rs.skip;
-    uint32_t next = rs.next;
+    uint32_t ridx = rs.run_index;
 
     const uint32_t mis = (uint32_t)(((uintptr_t)out >> 2) & 3u);  // values between the 16-byte grid and `out`
     uint32_t lo = 0;                                               // block positions [0, lo) are written
 
     while (lo < block_n) {
-        // ---- phase 1: runs covering [lo, hi) into the table, lane r <- run r ----------------------
-        uint32_t key = kNoRun, info = 0;  // this lane's entry: (start << 1 | kind), value or LDS bit position
-        uint32_t nruns = 0, o = lo;
-        while (o < block_n && nruns < kTableRuns - 1) {
-            if (rem == 0) {  // next run
-                if (next == kEndPos) {
-                    kind = kRle, rem = kRemMask, payload = 0;
-                    continue;
-                }
-                if (!win.holds(next & ~3u, (next & ~3u) + 24u)) {
-                    if (nruns) break;  // the table's runs still need the resident bytes: finish this pass first
-                    win.fill(rsrc, next, (((block_n - o) * w) >> 3) + 64u, lane);
-                }
-                const RunInfo run = decode_run(rd, next, end, w, n - (block_start + o));
-                if (run.kind >= kEnd) {  // exhausted (or a panic path, reported by parse_kernel): zeros
-                    next = kEndPos;
-                    continue;
-                }
-                kind = run.kind, rem = run.count, skip = 0, next = run.next;
-                payload = run.kind == kRle ? run.value : run.payload;
-                continue;
+        // ---- phase 1: the runs that cover [lo, hi) into the table ------------------------------------
+        const uint32_t est = (((block_n - lo) * w) >> 3) + 64u;  // bytes the rest of the block is expected to need
+        uint32_t take0 = min(rem, block_n - lo);
+        uint32_t info0 = payload;
+        bool alone = take0 == block_n - lo;  // the first run covers the rest of the block
+        if (kind == kBitpacked) {
+            const uint32_t b_lo = payload + (skip >> 3) * w;  // first byte of the group holding value `skip`
+            uint32_t b_hi = payload + ((skip + take0 + 7u) >> 3) * w + 8u;
+            if (!win.holds(b_lo & ~3u, b_hi)) {
+                if (take0 > kMaxVals) take0 = kMaxVals, alone = true;  // more than a window: this span only
+                b_hi = payload + ((skip + take0 + 7u) >> 3) * w + 8u;
+                win.fill(rsrc, b_lo, max(b_hi - b_lo + 16u, est), lane);
             }
-            uint32_t take = min(rem, block_n - o);
-            uint32_t value = payload;
-            if (kind == kBitpacked) {
-                const uint32_t b_lo = payload + (skip >> 3) * w;  // first byte of the group holding value `skip`
-                uint32_t b_hi = payload + ((skip + take + 7u) >> 3) * w + 8u;
-                if (!win.holds(b_lo & ~3u, b_hi)) {
-                    if (nruns) break;
-                    take = min(take, kMaxVals);
-                    b_hi = payload + ((skip + take + 7u) >> 3) * w + 8u;
-                    // stage what the rest of the block is expected to need, not just this span
-                    win.fill(rsrc, b_lo, max(b_hi - b_lo + 16u, (((block_n - o) * w) >> 3) + 64u), lane);
-                }
-                value = (b_lo - win.lo) * 8u + (skip & 7u) * w;  // LDS bit position of the run's value `skip`
+            info0 = (b_lo - win.lo) * 8u + (skip & 7u) * w;  // LDS bit position of the run's value `skip`
+        }
+        uint32_t hi = lo + take0;
+        uint32_t key = kNoRun, info = 0;  // lane r: table entry r + 1
+        uint32_t g = 0;                   // lanes [0, g) hold usable runs
+        uint32_t hp = kEndPos;
+        if (!alone) {
+            // lane r <- run ridx + 1 + r: position, header, length; a prefix sum places them
+            if (lane < kLaneRuns) hp = hdrs[ridx + 1u + lane];
+            const uint32_t hp0 = __builtin_amdgcn_readfirstlane(hp);
+            if (hp0 != kEndPos && !win.holds(hp0 & ~3u, (hp0 & ~3u) + 24u)) {
+                if (kind == kRle) win.fill(rsrc, hp0, est, lane);  // nothing of this pass lives in the window yet
             }
-            if (lane == nruns) {
-                key = (o << 1) | kind;
+            const bool valid = hp != kEndPos && hp >= win.lo && (hp & ~3u) + 24u <= win.hi;
+            LaneRun run;
+            run.kind = kRle, run.count = 0, run.info = 0;
+            if (valid) run = decode_lane<W>(win.lds, hp - win.lo, hp, end);
+            const uint32_t cnt = min(run.count, 2048u);
+            const uint32_t start = hi + wave_inclusive_sum(cnt, lane) - cnt;
+            bool ok = valid;
+            uint32_t value = run.info;
+            if (run.kind == kBitpacked) {
+                const uint32_t t = start < block_n ? min(run.count, block_n - start) : 0u;
+                ok = ok && run.info + ((t + 7u) >> 3) * w + 8u <= win.hi;
+                value = (run.info - win.lo) * 8u;
+            }
+            const uint64_t bad = __ballot(!ok);  // lane 63 is never valid
+            g = (uint32_t)__builtin_ctzll(bad);
+            const uint32_t start_g = __shfl(start, (int)g, 64);
+            const uint32_t hp_g = __shfl(hp, (int)g, 64);
+            const bool ends = g < kLaneRuns && hp_g == kEndPos;  // no more runs: zeros follow (mod.rs:95)
+            if (lane < g && start < block_n) {
+                key = (start << 1) | run.kind;
                 info = value;
             }
-            ++nruns;
-            o += take;
-            rem -= take;
-            skip += take;
+            if (ends && lane == g && start < block_n) key = (start << 1) | kRle;  // info stays 0
+            hi = (start_g >= block_n || ends) ? block_n : start_g;
         }
-        const uint32_t hi = o;  // this pass writes block positions [lo, hi)
-        tbl[lane] = make_uint2(key, info);
+        tbl[(lane + 1u) & 63u] = lane == 63u ? make_uint2((lo << 1) | kind, info0) : make_uint2(key, info);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
@@ -260,13 +277,37 @@ __device__ __forceinline__ void expand_block(const __amdgpu_buffer_rsrc_t rsrc, 
                     if (p + k >= (int32_t)lo && p + k < (int32_t)hi) out[p + k] = v[k];
             }
         }
+
+        // ---- next pass (rare: more than 63 runs in the block, or bytes beyond the window) -----------------
+        if (hi < block_n) {
+            if (alone) {  // the first run continues
+                rem -= take0;
+                skip += take0;
+            } else {  // run ridx + 1 + g becomes the first run
+                ridx += 1u + g;
+                const uint32_t at = __builtin_amdgcn_readfirstlane(hdrs[ridx]);
+                win.fill(rsrc, at, (((block_n - hi) * w) >> 3) + 64u, lane);
+                auto rd = [&](uint32_t a) -> uint32_t { return __builtin_amdgcn_readfirstlane(win.dword(a)); };
+                const RunInfo run = decode_run(rd, at, end, w, n - (block_start + hi));
+                if (run.kind >= kEnd || run.count == 0) {  // cannot happen for a listed run; ends the block safely
+                    kind = kRle, rem = kRemMask, payload = 0, skip = 0;
+                } else {
+                    kind = run.kind, rem = run.count, skip = 0;
+                    payload = run.kind == kRle ? run.value : run.payload;
+                }
+            }
+        }
         lo = hi;
     }
 }
 
-__global__ __launch_bounds__(256, 8) void expand_kernel(const PageDev *__restrict__ pages,
+#ifndef PQ2_EXPAND_WAVES
+#define PQ2_EXPAND_WAVES 6  // 75 VGPRs fit without spilling; 8 waves per SIMD would spill to scratch
+#endif
+__global__ __launch_bounds__(256, PQ2_EXPAND_WAVES) void expand_kernel(const PageDev *__restrict__ pages,
                                                        const uint32_t *__restrict__ tile_page,
-                                                       const Resume *__restrict__ resume) {
+                                                       const Resume *__restrict__ resume,
+                                                       const uint32_t *__restrict__ run_pos) {
     __shared__ __attribute__((aligned(16))) uint8_t stage[kBlocksPerTile * kWinBytes];
     __shared__ __attribute__((aligned(16))) uint2 table[kBlocksPerTile * (kTableRuns + 2)];
 
@@ -282,7 +323,7 @@ __global__ __launch_bounds__(256, 8) void expand_kernel(const PageDev *__restric
     const uint32_t block_n = min(kBlockValues, n - block_start);
 
     Resume rs = resume[(size_t)tile * kBlocksPerTile + wave];
-    rs.next = __builtin_amdgcn_readfirstlane(rs.next);
+    rs.run_index = __builtin_amdgcn_readfirstlane(rs.run_index);
     rs.rem_kind = __builtin_amdgcn_readfirstlane(rs.rem_kind);
     rs.payload = __builtin_amdgcn_readfirstlane(rs.payload);
     rs.skip = __builtin_amdgcn_readfirstlane(rs.skip);
@@ -301,7 +342,7 @@ __global__ __launch_bounds__(256, 8) void expand_kernel(const PageDev *__restric
     switch (pg.num_bits) {
 #define PQ2_W(N)                                                                             \
     case N:                                                                                  \
-        expand_block<N>(rsrc, win, tbl, rs, end, n, block_start, block_n, out, lane);        \
+        expand_block<N>(rsrc, win, tbl, rs, run_pos + pg.run_base, end, n, block_start, block_n, out, lane); \
         break;
         PQ2_W(1) PQ2_W(2) PQ2_W(3) PQ2_W(4) PQ2_W(5) PQ2_W(6) PQ2_W(7) PQ2_W(8)
         PQ2_W(9) PQ2_W(10) PQ2_W(11) PQ2_W(12) PQ2_W(13) PQ2_W(14) PQ2_W(15) PQ2_W(16)
@@ -345,18 +386,18 @@ __global__ __launch_bounds__(256) void bitunpack_kernel(uint64_t in_addr, uint32
 
 // ---- launchers (called from pq2_api.cpp) ----------------------------------------
 extern "C" hipError_t pq2_launch_parse(const void *pages, uint32_t n_pages, void *resume, uint32_t *tile_page,
-                                       int32_t *status, hipStream_t stream) {
+                                       uint32_t *run_pos, int32_t *status, hipStream_t stream) {
     if (n_pages == 0) return hipSuccess;
     hipLaunchKernelGGL(pq2::parse_kernel, dim3(n_pages), dim3(64), 0, stream, (const pq2::PageDev *)pages, n_pages,
-                       (pq2::Resume *)resume, tile_page, status);
+                       (pq2::Resume *)resume, tile_page, run_pos, status);
     return hipGetLastError();
 }
 
 extern "C" hipError_t pq2_launch_expand(const void *pages, const uint32_t *tile_page, uint32_t n_tiles,
-                                        const void *resume, hipStream_t stream) {
+                                        const void *resume, const uint32_t *run_pos, hipStream_t stream) {
     if (n_tiles == 0) return hipSuccess;
     hipLaunchKernelGGL(pq2::expand_kernel, dim3(n_tiles), dim3(256), 0, stream, (const pq2::PageDev *)pages,
-                       tile_page, (const pq2::Resume *)resume);
+                       tile_page, (const pq2::Resume *)resume, run_pos);
     return hipGetLastError();
 }
 

@@ -45,7 +45,7 @@ extern "C" {
 #define PQ2_BLOCK_VALUES 1024u
 /* Largest num_values / packed length a single page may have. */
 #define PQ2_MAX_PAGE_VALUES 0x7fffffffu
-#define PQ2_MAX_PAGE_BYTES 0xffffff00u
+#define PQ2_MAX_PAGE_BYTES 0xfff00000u
 
 typedef struct pq2_ctx pq2_ctx;
 

@@ -27,17 +27,43 @@
 
 namespace pq2 {
 
-constexpr uint32_t kHalf = 4096;  // bytes per ring half
-constexpr uint32_t kRing = 2 * kHalf;
+constexpr uint32_t kHalf = 4096;    // bytes the stream window of parse_kernel advances by
+constexpr uint32_t kWin = 2 * kHalf;  // bytes of the window
 
 // ---------------------------------------------------------------------------
 // parse_kernel
+//
+// Finding the headers is a chain of dependent steps (LDS read of a header ->
+// position of the next header -> LDS read ...), so one wave per page walks it
+// with all lanes holding the same values, and since a single wave issues one
+// instruction every four cycles the walk is written for instruction count:
+//
+//   chase   per run: one unaligned 8-byte LDS read (a header of 1..2 bytes and
+//           the bytes behind it), the scalar arithmetic that yields the next
+//           header's position, and three v_writelane that park (position, 8
+//           bytes) in lane i of a register batch; 30 instructions, written in
+//           assembly.  The read of the next header is issued before the checks
+//           and the parking of the current one.  Longer varints, runs cut by
+//           the end of the stream and the end itself leave the loop and go
+//           through decode_run, which parks an explicit record.
+//   place   once per 64 parked runs, lane-parallel: every lane decodes its
+//           run, a wave-wide prefix sum of the run lengths gives each run its
+//           output offset, runs that yield values get their slot in the
+//           header-position list, and the runs that cover the first value of a
+//           1024-value block write that block's Resume entry.
+//
+// The chase does not know how many values it has passed; the place step stops
+// the page once num_values are covered, so at most one batch of headers behind
+// the last needed one is looked at (and never reported: a header the reference
+// would not reach cannot fail the page).
 // ---------------------------------------------------------------------------
+constexpr uint32_t kExplicit = 0x8080u;  // `lo` of a parked record that carries (kind, count, info) itself
+
 __global__ __launch_bounds__(64) void parse_kernel(const PageDev *__restrict__ pages, uint32_t n_pages,
                                                    Resume *__restrict__ resume, uint32_t *__restrict__ tile_page,
                                                    uint32_t *__restrict__ run_pos, int32_t *__restrict__ status) {
-    // ring[a & (kRing-1)] holds stream byte a for a in [win_lo, win_lo + kRing)
-    __shared__ __attribute__((aligned(16))) uint8_t ring[kRing];
+    // win[a - win_lo] holds stream byte a for a in [win_lo, win_lo + kWin)
+    __shared__ __attribute__((aligned(16))) uint8_t win[kWin];
 
     const uint32_t lane = threadIdx.x;
     const uint32_t page = blockIdx.x;
@@ -56,10 +82,10 @@ __global__ __launch_bounds__(64) void parse_kernel(const PageDev *__restrict__ p
         tile_page[pg.tile_base + t] = page;
 
     uint32_t *const hdrs = run_pos + pg.run_base;  // header positions of the runs that yield values
-    uint32_t n_runs = 0;                           // entries of `hdrs` produced so far
-    uint32_t pend = 0;                             // lane i holds entry (n_runs & ~63) + i until 64 are complete
+    uint32_t n_runs = 0;                           // entries of `hdrs` written so far
+    uint32_t produced = 0;                         // values those runs yield
 
-    // entries [from, n_blocks): the stream is exhausted, zeros follow (mod.rs:95); closes the header list
+    // blocks [from, n_blocks): the stream is exhausted, zeros follow (mod.rs:95); closes the header list
     auto fill_end = [&](uint32_t from) {
         Resume e;
         e.run_index = n_runs;
@@ -67,8 +93,7 @@ __global__ __launch_bounds__(64) void parse_kernel(const PageDev *__restrict__ p
         e.payload = 0;
         e.skip = 0;
         for (uint32_t b = from + lane; b < n_blocks; b += 64) entries[b] = e;
-        if (lane == (n_runs & 63u)) pend = kEndPos;
-        if (lane <= (n_runs & 63u)) hdrs[(n_runs & ~63u) + lane] = pend;
+        if (lane == 0) hdrs[n_runs] = kEndPos;
     };
 
     if (w == 0 || pg.in_len == 0 || w > 32) {  // decoder.rs:31-37: nothing to iterate
@@ -81,80 +106,217 @@ __global__ __launch_bounds__(64) void parse_kernel(const PageDev *__restrict__ p
     const uint64_t base16 = pg.in_addr - delta;
     const uint32_t end = delta + pg.in_len;  // a-offset one past the last stream byte
     const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(base16, (end + 3u) & ~3u);
+    const uint32_t rb = ceil8(w);                                    // bytes of an RLE value
+    const uint32_t rb_mask = rb < 4 ? (1u << (rb * 8u)) - 1u : ~0u;  // the first min(4, rb) of them
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)win;
 
-    u32x4 pre[4];              // prefetched half [win_lo + kRing, win_lo + kRing + kHalf)
-    uint32_t win_lo = 0;       // a-offset (multiple of kHalf) of the first resident byte
-    bool have_window = false;  // false until the first load
+    u32x4 pre[4];         // prefetched half [win_lo + kWin, win_lo + kWin + kHalf)
+    uint32_t win_lo = 0;  // a-offset (multiple of kHalf) of the first resident byte
 
     auto load_half = [&](uint32_t half_a, u32x4 *r) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             r[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, half_a + (uint32_t)i * 1024u + lane * 16u, 0, 0);
     };
-    auto store_half = [&](uint32_t half_a, const u32x4 *r) {
-        const uint32_t slot = half_a & (kRing - 1);
+    auto store_half = [&](uint32_t slot, const u32x4 *r) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *(u32x4 *)&ring[slot + (uint32_t)i * 1024u + lane * 16u] = r[i];
+        for (int i = 0; i < 4; ++i) *(u32x4 *)&win[slot + (uint32_t)i * 1024u + lane * 16u] = r[i];
     };
-    // makes [pos & ~3, (pos & ~3) + 24) resident: decode_run reads at most 22 bytes from pos
-    auto ensure = [&](uint32_t pos) {
-        const uint32_t need_hi = (pos & ~3u) + 24u;
-        if (have_window && pos >= win_lo && need_hi <= win_lo + kRing) return;
-        __syncthreads();  // every earlier ring read of the wave is done before the ring is overwritten
-        if (have_window && pos >= win_lo && need_hi <= win_lo + kRing + kHalf) {
-            // slide by one half: the prefetched half replaces the oldest one
-            store_half(win_lo + kRing, pre);
+    // moves the window so that [at, at + 32) is resident; at >= win_lo + kHalf
+    auto slide = [&](uint32_t at) {
+        __syncthreads();  // every earlier window read of the wave is done before the window is overwritten
+        if (at - win_lo + 32u <= kWin + kHalf) {
+            // by one half: the upper half moves down, the prefetched half becomes the upper one
+            u32x4 up[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) up[i] = *(const u32x4 *)&win[kHalf + (uint32_t)i * 1024u + lane * 16u];
+            store_half(0, up);
+            store_half(kHalf, pre);
             win_lo += kHalf;
         } else {
-            // first load, or a run that jumped beyond the prefetched half
-            win_lo = pos & ~(kHalf - 1);
+            // a run that jumped beyond the prefetched half
+            win_lo = at & ~(kHalf - 1);
             u32x4 a[4], b[4];
             load_half(win_lo, a);
             load_half(win_lo + kHalf, b);
-            store_half(win_lo, a);
-            store_half(win_lo + kHalf, b);
-            have_window = true;
+            store_half(0, a);
+            store_half(kHalf, b);
         }
-        load_half(win_lo + kRing, pre);  // lands while the chase works through the window
+        load_half(win_lo + kWin, pre);  // lands while the chase works through the window
         __syncthreads();
     };
+    auto resident = [&](uint32_t at, uint32_t bytes) { return at - win_lo + bytes <= kWin; };  // at >= win_lo
     auto rd = [&](uint32_t a) -> uint32_t {
-        return __builtin_amdgcn_readfirstlane(*(const uint32_t *)&ring[a & (kRing - 1)]);
+        return __builtin_amdgcn_readfirstlane(*(const uint32_t *)&win[a - win_lo]);
     };
 
-    uint32_t pos = delta;
-    uint32_t produced = 0;
-    uint32_t next_block = 0;  // blocks < next_block have their entry; next_block * 1024 >= produced
+    {  // first window
+        u32x4 a[4], b[4];
+        load_half(0, a);
+        load_half(kHalf, b);
+        load_half(kWin, pre);
+        store_half(0, a);
+        store_half(kHalf, b);
+        __syncthreads();
+    }
+
+    uint32_t pos = delta;  // a-offset of the next header
     int32_t st = 0;
-    while (produced < n) {
-        ensure(pos);
-        const RunInfo run = decode_run(rd, pos, end, w, n - produced);
-        if (run.kind >= kEnd) {
-            if (run.kind == kPanic) st = 5;  // PQ2_REFERENCE_WOULD_PANIC
+    for (;;) {
+        // ---- chase: park up to 64 runs, record i in lane i --------------------------------------------
+        uint32_t r_pos = 0, r_lo = 0, r_hi = 0, r_info = 0;
+        uint32_t m = 0;     // parked records
+        uint32_t term = 0;  // kEnd / kPanic once the chase cannot go on
+        for (;;) {
+            // Runs whose header has one or two bytes (uleb128.rs:3-23) and which lie inside the stream
+            // (decoder.rs:44-63): next = pos + header bytes + (bit-packed ? (header >> 1) * w : ceil8(w)).
+            // why: 0 = 64 records parked; 1 = the header at pos is not of that kind (nothing parked for it);
+            // 2 = a record was parked but the next header's 8 bytes are not all in the window.
+            uint32_t why, lo, hi, groups, t, bytes, nm1, addr;  // nm1: the next header's position minus one
+            const uint32_t voff = lds_base - win_lo;
+            asm volatile(
+                "v_add_u32 %[addr], %[pos], %[voff]\n\t"
+                "ds_read_b64 v[2:3], %[addr]\n"
+                "1:\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "v_readfirstlane_b32 %[lo], v2\n\t"
+                "v_readfirstlane_b32 %[hi], v3\n\t"
+                "s_bfe_u32 %[groups], %[lo], 0x60001\n\t"
+                "s_lshr_b32 %[t], %[lo], 2\n\t"
+                "s_and_b32 %[t], %[t], 0x1fc0\n\t"
+                "s_bitcmp1_b32 %[lo], 7\n\t"
+                "s_cselect_b32 %[t], %[t], 0\n\t"
+                "s_or_b32 %[groups], %[groups], %[t]\n\t"
+                "s_mul_i32 %[bytes], %[groups], %[w]\n\t"
+                "s_bitcmp1_b32 %[lo], 0\n\t"
+                "s_cselect_b32 %[bytes], %[bytes], %[rb]\n\t"
+                "s_bitcmp1_b32 %[lo], 7\n\t"
+                "s_addc_u32 %[nm1], %[pos], %[bytes]\n\t"
+                "v_add_u32 %[addr], %[nm1], %[voff1]\n\t"
+                "ds_read_b64 v[2:3], %[addr]\n\t"
+                "s_andn2_b32 %[t], 0x8080, %[lo]\n\t"
+                "s_cbranch_scc0 2f\n\t"
+                "s_cmp_gt_u32 %[nm1], %[end_m1]\n\t"
+                "s_cbranch_scc1 2f\n\t"
+                "s_mov_b32 m0, %[m]\n\t"
+                "v_writelane_b32 %[r_pos], %[pos], m0\n\t"
+                "v_writelane_b32 %[r_lo], %[lo], m0\n\t"
+                "v_writelane_b32 %[r_hi], %[hi], m0\n\t"
+                "s_add_u32 %[m], %[m], 1\n\t"
+                "s_add_u32 %[pos], %[nm1], 1\n\t"
+                "s_cmp_gt_u32 %[nm1], %[lim_m1]\n\t"
+                "s_cbranch_scc1 3f\n\t"
+                "s_cmp_lt_u32 %[m], 64\n\t"
+                "s_cbranch_scc1 1b\n\t"
+                "s_mov_b32 %[why], 0\n\t"
+                "s_branch 4f\n"
+                "2:\n\t"
+                "s_mov_b32 %[why], 1\n\t"
+                "s_branch 4f\n"
+                "3:\n\t"
+                "s_mov_b32 %[why], 2\n"
+                "4:\n\t"
+                "s_waitcnt lgkmcnt(0)"
+                : [pos] "+s"(pos), [m] "+s"(m), [r_pos] "+v"(r_pos), [r_lo] "+v"(r_lo), [r_hi] "+v"(r_hi),
+                  [why] "=&s"(why), [lo] "=&s"(lo), [hi] "=&s"(hi), [groups] "=&s"(groups), [t] "=&s"(t),
+                  [bytes] "=&s"(bytes), [nm1] "=&s"(nm1), [addr] "=&v"(addr)
+                : [w] "s"(w), [rb] "s"(rb), [end_m1] "s"(end - 1u), [lim_m1] "s"(win_lo + kWin - 9u), [voff] "v"(voff),
+                  [voff1] "v"(voff + 1u)
+                : "v2", "v3", "scc", "memory");
+            if (why == 0u) break;
+            if (why == 1u) {
+                // three or more header bytes, a run cut by the end of the stream, or the end itself
+                if (!resident(pos, 32u)) slide(pos);
+                const RunInfo run = decode_run(rd, pos, end, w, 0xffffffffu);
+                const uint32_t e_lo = kExplicit | (run.kind << 16);
+                const uint32_t e_hi = __builtin_amdgcn_readfirstlane(run.count);
+                const uint32_t e_info = __builtin_amdgcn_readfirstlane(run.kind == kRle ? run.value : run.payload);
+                // v_writelane_b32 ignores EXEC; it may read one scalar register only, so the lane goes through M0
+                asm volatile(
+                    "s_mov_b32 m0, %[m]\n\t"
+                    "v_writelane_b32 %[r_pos], %[pos], m0\n\t"
+                    "v_writelane_b32 %[r_lo], %[e_lo], m0\n\t"
+                    "v_writelane_b32 %[r_hi], %[e_hi], m0\n\t"
+                    "v_writelane_b32 %[r_info], %[e_info], m0"
+                    : [r_pos] "+v"(r_pos), [r_lo] "+v"(r_lo), [r_hi] "+v"(r_hi), [r_info] "+v"(r_info)
+                    : [m] "s"(m), [pos] "s"(pos), [e_lo] "s"(e_lo), [e_hi] "s"(e_hi), [e_info] "s"(e_info));
+                ++m;
+                if (run.kind >= kEnd) {
+                    term = run.kind;
+                    break;
+                }
+                pos = run.next;
+            }
+            if (!resident(pos, 8u)) slide(pos);
+            if (m == 64u) break;
+        }
+
+        // ---- place: lane i decodes record i; a prefix sum over the run lengths places the runs -------------
+        uint32_t kind, count, info;
+        {
+            const uint32_t two = (r_lo >> 7) & 1u;
+            const uint32_t groups = ((r_lo >> 1) & 0x3fu) | (two ? (r_lo >> 2) & 0x1fc0u : 0u);
+            const uint32_t rest =
+                two ? __builtin_amdgcn_alignbit(r_hi, r_lo, 16) : __builtin_amdgcn_alignbit(r_hi, r_lo, 8);
+            kind = (r_lo & 1u) ^ 1u;
+            count = kind == kRle ? groups : groups * 8u;         // mod.rs:41-64
+            info = kind == kRle ? (rest & rb_mask) : r_pos + 1u + two;  // RLE value (not masked to w) | payload
+        }
+        if ((~r_lo & kExplicit) == 0u) {
+            kind = (r_lo >> 16) & 3u;
+            count = r_hi;
+            info = r_info;
+        }
+        const uint32_t left = n - produced;  // > 0
+        const uint32_t cnt = (lane < m && kind < kEnd) ? min(count, left) : 0u;
+        uint32_t incl = cnt;  // inclusive prefix sum, saturating at `left` (all terms <= left < 2^31)
+#pragma unroll
+        for (uint32_t d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d, 64);
+            if (lane >= d) incl = min(incl + up, left);
+        }
+        uint32_t before = __shfl_up(incl, 1, 64);
+        if (lane == 0) before = 0;
+        const uint32_t eff = min(cnt, left - before);  // the page ends inside or before this run: mod.rs:76-78
+        const bool yields = eff > 0u;
+        const uint64_t ymask = __ballot(yields);
+        const uint32_t idx =
+            n_runs + __builtin_amdgcn_mbcnt_hi((uint32_t)(ymask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ymask, 0u));
+        if (yields) hdrs[idx] = r_pos;
+        // the run holds values [first, first + eff) of the page: it starts blocks b_first..b_last (if any)
+        const uint32_t first = produced + before;
+        const uint32_t b_first = (first + kBlockValues - 1u) / kBlockValues;
+        const uint32_t b_last = (first + eff - 1u) / kBlockValues;  // meaningful where `yields`
+        const uint32_t nb = (yields && b_last >= b_first) ? b_last - b_first + 1u : 0u;
+        auto write_entries = [&](uint32_t b_from, uint32_t b_step, uint32_t b_to, uint32_t run_index,
+                                 uint32_t run_first, uint32_t run_eff, uint32_t run_kind, uint32_t run_info) {
+            for (uint32_t b = b_from; b <= b_to; b += b_step) {
+                const uint32_t skip = b * kBlockValues - run_first;
+                Resume e;
+                e.run_index = run_index;
+                e.rem_kind = (run_eff - skip) | (run_kind << 31);
+                e.payload = run_info;
+                e.skip = skip;
+                entries[b] = e;
+            }
+        };
+        if (nb != 0u && nb <= 4u) write_entries(b_first, 1u, b_last, idx, first, eff, kind, info);
+        for (uint64_t big = __ballot(nb > 4u); big != 0; big &= big - 1) {  // long runs: the whole wave writes
+            const uint32_t l = (uint32_t)__builtin_ctzll(big);
+            write_entries(__builtin_amdgcn_readlane(b_first, l) + lane, 64u, __builtin_amdgcn_readlane(b_last, l),
+                          __builtin_amdgcn_readlane(idx, l), __builtin_amdgcn_readlane(first, l),
+                          __builtin_amdgcn_readlane(eff, l), __builtin_amdgcn_readlane(kind, l),
+                          __builtin_amdgcn_readlane(info, l));
+        }
+        n_runs += (uint32_t)__popcll(ymask);
+        produced += __builtin_amdgcn_readlane(incl, 63);
+        if (produced >= n) break;
+        if (term != 0u) {
+            if (term == kPanic) st = 5;  // PQ2_REFERENCE_WOULD_PANIC
             break;
         }
-        if (run.count > 0) {
-            if (lane == (n_runs & 63u)) pend = pos;
-            if ((n_runs & 63u) == 63u) hdrs[(n_runs & ~63u) + lane] = pend;  // 64 positions, one coalesced store
-            const uint32_t last_block = (produced + run.count - 1) / kBlockValues;
-            if (last_block >= next_block) {
-                for (uint32_t b = next_block + lane; b <= last_block; b += 64) {
-                    const uint32_t skip = b * kBlockValues - produced;
-                    Resume e;
-                    e.run_index = n_runs;
-                    e.rem_kind = (run.count - skip) | (run.kind << 31);
-                    e.payload = run.kind == kRle ? run.value : run.payload;
-                    e.skip = skip;
-                    entries[b] = e;
-                }
-                next_block = last_block + 1;
-            }
-            ++n_runs;
-        }
-        produced += run.count;
-        pos = run.next;
     }
-    fill_end(next_block);
+    fill_end((produced + kBlockValues - 1u) / kBlockValues);
     if (lane == 0) status[page] = st;
 }
 

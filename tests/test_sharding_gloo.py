@@ -40,7 +40,7 @@ WORKER = textwrap.dedent("""
     assert abs(t.item() - 0.001 * world) < 1e-12
     dist.barrier()
     dist.destroy_process_group()
-    print("rank", rank, "ok", lo, hi)
+    open(os.path.join(os.environ["PQ2_TEST_OUT"], "rank%d.ok" % rank), "w").write("%d %d" % (lo, hi))
 """) % ROOT
 
 
@@ -52,8 +52,8 @@ def test_two_ranks_shard_pages_with_gloo(tmp_path):
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
            "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
-    env = dict(os.environ, OMP_NUM_THREADS="1")
+    env = dict(os.environ, OMP_NUM_THREADS="1", PQ2_TEST_OUT=str(tmp_path))
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stdout + out.stderr
-    text = out.stdout + out.stderr
-    assert text.count(" ok ") == 2, text
+    ranges = [tuple(int(v) for v in (tmp_path / ("rank%d.ok" % r)).read_text().split()) for r in range(2)]
+    assert ranges[0][0] == 0 and ranges[0][1] == ranges[1][0] and ranges[1][1] == 301

@@ -40,7 +40,7 @@ WORKER = textwrap.dedent("""
     assert abs(t.item() - 0.001 * world) < 1e-12
     dist.barrier()
     dist.destroy_process_group()
-    open(os.path.join(os.environ["PQ2_TEST_OUT"], "rank%d.ok" % rank), "w").write("%d %d" % (lo, hi))
+    open(os.path.join(os.environ["PQ2_TEST_OUT"], "rank%%d.ok" %% rank), "w").write("%%d %%d" %% (lo, hi))
 """) % ROOT
 
 

@@ -68,11 +68,15 @@ const char *pq2_strerror(int32_t status);
 const char *pq2_last_error(const pq2_ctx *ctx);
 
 /* Kernel timing for benchmarks (no counterpart in the reference).  While
- * enabled, every batch records HIP events on its stream around the parse and
- * the expand kernel; pq2_ctx_kernel_times waits for them, returns the summed
- * durations in milliseconds with the number of batches, and resets the sums. */
+ * enabled, every kernel launch of a batch is bracketed by HIP events on the
+ * stream it runs on (a large batch is decoded in several rounds, each one
+ * parse and one expand launch, on two internal streams).
+ * pq2_ctx_kernel_times waits for them, returns the summed durations in
+ * milliseconds with the number of batches and (if expand_launches is not
+ * NULL) of expand launches, and resets the sums. */
 int32_t pq2_ctx_enable_profiling(pq2_ctx *ctx, int32_t on);
-int32_t pq2_ctx_kernel_times(pq2_ctx *ctx, double *parse_ms, double *expand_ms, uint64_t *batches);
+int32_t pq2_ctx_kernel_times(pq2_ctx *ctx, double *parse_ms, double *expand_ms, uint64_t *batches,
+                             uint64_t *expand_launches);
 
 /* ---- hybrid RLE / bit-packed decode -------------------------------------- */
 

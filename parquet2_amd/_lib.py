@@ -53,7 +53,7 @@ SIGNATURES = {
     "pq2_strerror": (C.c_char_p, [C.c_int32]),
     "pq2_last_error": (C.c_char_p, [C.c_void_p]),
     "pq2_ctx_enable_profiling": (C.c_int32, [C.c_void_p, C.c_int32]),
-    "pq2_ctx_kernel_times": (C.c_int32, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), u64p]),
+    "pq2_ctx_kernel_times": (C.c_int32, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), u64p, u64p]),
     "pq2_decode_batch_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p,
                                              C.c_uint64, C.c_void_p, C.c_void_p]),
     "pq2_fetch_status": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64]),
@@ -148,10 +148,10 @@ class Context:
         self._check(lib().pq2_ctx_enable_profiling(self._h, int(on)))
 
     def kernel_times(self):
-        """(parse_ms, expand_ms, batches) summed since the last call."""
-        a, b, n = C.c_double(), C.c_double(), C.c_uint64()
-        self._check(lib().pq2_ctx_kernel_times(self._h, C.byref(a), C.byref(b), C.byref(n)))
-        return a.value, b.value, n.value
+        """(parse_ms, expand_ms, batches, expand_launches) summed since the last call."""
+        a, b, n, k = C.c_double(), C.c_double(), C.c_uint64(), C.c_uint64()
+        self._check(lib().pq2_ctx_kernel_times(self._h, C.byref(a), C.byref(b), C.byref(n), C.byref(k)))
+        return a.value, b.value, n.value, k.value
 
     # ---- device-resident batch decode --------------------------------------
     def decode_batch_device(self, d_in_ptr, in_bytes, descs, d_out_ptr, out_values, stream=0, want_status=True):

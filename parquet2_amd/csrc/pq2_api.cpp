@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -19,9 +20,9 @@
 
 extern "C" {
 hipError_t pq2_launch_parse(const void *pages, uint32_t n_pages, void *resume, uint32_t *tile_page, uint32_t *run_pos,
-                            int32_t *status, hipStream_t stream);
-hipError_t pq2_launch_expand(const void *pages, const uint32_t *tile_page, uint32_t n_tiles, const void *resume,
-                             const uint32_t *run_pos, hipStream_t stream);
+                            int32_t *status, void *state, uint32_t round, hipStream_t stream);
+hipError_t pq2_launch_expand(const void *pages, const uint32_t *tile_page, uint32_t tile_start, uint32_t n_tiles,
+                             const void *resume, const uint32_t *run_pos, uint32_t round, hipStream_t stream);
 hipError_t pq2_launch_bitunpack(const void *d_packed, uint32_t packed_len, uint32_t num_bits, uint32_t length,
                                 uint32_t *d_out, hipStream_t stream);
 }
@@ -30,6 +31,9 @@ namespace {
 
 constexpr uint32_t kTileValues = 4096;  // 4 blocks of PQ2_BLOCK_VALUES
 constexpr uint32_t kBlocksPerTile = 4;
+constexpr uint32_t kRounds = 4;          // must match pq2::kRounds
+constexpr uint64_t kMinRoundedTiles = 16384;  // batches below 64 Mi values are decoded in one round
+constexpr size_t kParseStateBytes = 16;  // sizeof(pq2::ParseState)
 
 struct PageDev {  // must match pq2::PageDev
     uint64_t in_addr;
@@ -38,9 +42,11 @@ struct PageDev {  // must match pq2::PageDev
     uint32_t in_len;
     uint32_t num_values;
     uint32_t num_bits;
-    uint32_t tile_base;
+    uint32_t round_tile[kRounds];
+    uint32_t tile_base[kRounds];
+    uint32_t reserved;
 };
-static_assert(sizeof(PageDev) == 40, "PageDev layout");
+static_assert(sizeof(PageDev) == 72, "PageDev layout");
 
 struct DevBuf {
     void *ptr = nullptr;
@@ -57,17 +63,29 @@ struct pq2_ctx {
     size_t h_meta_cap = 0;
     hipEvent_t meta_copied = nullptr;  // the previous upload has left h_meta
     bool meta_in_flight = false;
-    DevBuf d_meta, d_status, d_resume, d_tile_page, d_run_pos;
+    DevBuf d_meta, d_status, d_resume, d_tile_page, d_run_pos, d_state;
+    // Where the rounds of a page end, as fractions of its tiles (the last round ends with the page).  The parts
+    // grow because round r + 1 is parsed while round r is expanded, and parsing is the faster of the two; the
+    // first part is small because nothing hides its parse.  Tuning knobs: PQ2_ROUND_SPLIT="a,b,c",
+    // PQ2_MIN_ROUNDED_TILES.
+    double round_split[kRounds - 1] = {0.25, 1.0, 1.0};
+    uint64_t min_rounded_tiles = kMinRoundedTiles;
+    // rounds: parse_kernel of round r + 1 runs on parse_stream while expand_kernel of round r runs on expand_stream
+    hipStream_t parse_stream = nullptr, expand_stream = nullptr;
+    hipEvent_t fork = nullptr, parsed[4] = {nullptr, nullptr, nullptr, nullptr}, parse_joined = nullptr,
+               expand_joined = nullptr;
     std::vector<int32_t> host_status;  // statuses decided on the host (bad num_bits)
     uint64_t last_n_pages = 0;
     hipStream_t last_stream = nullptr;
     bool busy = false;  // a batch may still be running on last_stream
     // optional kernel timing (pq2_ctx_enable_profiling): events around parse and expand of every batch
     bool profiling = false;
-    struct Stamp {
-        hipEvent_t e[3];
+    struct Stamp {  // one kernel launch
+        hipEvent_t begin, end;
+        bool expand;
     };
     std::vector<Stamp> stamps;
+    uint64_t stamped_batches = 0;
     // host-buffer path
     DevBuf d_in, d_out;
     hipStream_t copy_streams[3] = {nullptr, nullptr, nullptr};
@@ -161,18 +179,52 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
             ctx->host_status[i] = PQ2_INVALID_PARAMETER;
             p.num_values = 0;
         }
-        p.tile_base = static_cast<uint32_t>(tiles);
+        const uint64_t page_tiles = (uint64_t(p.num_values) + kTileValues - 1) / kTileValues;
+        p.reserved = 0;
         // header-position list: a run that yields values takes >= 2 stream bytes and >= 1 value; + the closing
         // entry, + the 64 entries a wave may read past the last one, rounded to whole 64-entry stores
         p.run_base = run_entries;
         run_entries += (std::min<uint64_t>(p.num_values, d.in_len / 2) + 1 + 64 + 63) & ~uint64_t(63);
-        tiles += (p.num_values + kTileValues - 1) / kTileValues;
+        tiles += page_tiles;
         if (tiles > 0x7fffffffull) return fail(ctx, PQ2_INVALID_PARAMETER, "batch too large for one launch");
     }
     if ((reinterpret_cast<uintptr_t>(d_out) & 3u) != 0) return fail(ctx, PQ2_INVALID_PARAMETER, "d_out misaligned");
 
+    // tiles are numbered round-major: all tiles of round 0 of all pages, then round 1, ...
+    const bool split = tiles >= ctx->min_rounded_tiles;
+    uint64_t round_start[kRounds + 1] = {0};
+    for (uint64_t i = 0; i < n_pages; ++i) {
+        PageDev &p = pages[i];
+        const uint64_t t = (uint64_t(p.num_values) + kTileValues - 1) / kTileValues;
+        p.round_tile[0] = 0;
+        for (uint32_t r = 1; r < kRounds; ++r) {
+            const uint64_t first = split ? static_cast<uint64_t>(ctx->round_split[r - 1] * double(t) + 0.5) : t;
+            p.round_tile[r] = static_cast<uint32_t>(std::min(t, std::max<uint64_t>(first, p.round_tile[r - 1])));
+        }
+        for (uint32_t r = 0; r < kRounds; ++r)
+            round_start[r + 1] += (r + 1 < kRounds ? p.round_tile[r + 1] : t) - p.round_tile[r];
+    }
+    uint32_t rounds = 1;
+    for (uint32_t r = 0; r < kRounds; ++r) {
+        if (round_start[r + 1] > 0) rounds = r + 1;
+        round_start[r + 1] += round_start[r];
+    }
+    {
+        uint64_t next[kRounds];
+        for (uint32_t r = 0; r < kRounds; ++r) next[r] = round_start[r];
+        for (uint64_t i = 0; i < n_pages; ++i) {
+            PageDev &p = pages[i];
+            const uint64_t t = (uint64_t(p.num_values) + kTileValues - 1) / kTileValues;
+            for (uint32_t r = 0; r < kRounds; ++r) {
+                p.tile_base[r] = static_cast<uint32_t>(next[r]);
+                next[r] += (r + 1 < kRounds ? p.round_tile[r + 1] : t) - p.round_tile[r];
+            }
+        }
+    }
+
     if ((st = reserve(ctx, ctx->d_meta, meta_bytes))) return st;
     if ((st = reserve(ctx, ctx->d_status, n_pages * sizeof(int32_t)))) return st;
+    if ((st = reserve(ctx, ctx->d_state, n_pages * kParseStateBytes))) return st;
     if ((st = reserve(ctx, ctx->d_resume, std::max<uint64_t>(tiles, 1) * kBlocksPerTile * 16))) return st;
     if ((st = reserve(ctx, ctx->d_tile_page, std::max<uint64_t>(tiles, 1) * sizeof(uint32_t)))) return st;
     if ((st = reserve(ctx, ctx->d_run_pos, std::max<uint64_t>(run_entries, 1) * sizeof(uint32_t)))) return st;
@@ -183,21 +235,64 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
 
     const PageDev *d_pages = static_cast<const PageDev *>(ctx->d_meta.ptr);
     uint32_t *d_tile_page = static_cast<uint32_t *>(ctx->d_tile_page.ptr);
-    pq2_ctx::Stamp stamp{};
-    if (ctx->profiling) {
-        for (auto &e : stamp.e) PQ2_HIP(ctx, hipEventCreate(&e));
-        PQ2_HIP(ctx, hipEventRecord(stamp.e[0], stream));
-    }
     uint32_t *d_run_pos = static_cast<uint32_t *>(ctx->d_run_pos.ptr);
-    PQ2_HIP(ctx, pq2_launch_parse(d_pages, static_cast<uint32_t>(n_pages), ctx->d_resume.ptr, d_tile_page, d_run_pos,
-                                  static_cast<int32_t *>(ctx->d_status.ptr), stream));
-    if (ctx->profiling) PQ2_HIP(ctx, hipEventRecord(stamp.e[1], stream));
-    PQ2_HIP(ctx, pq2_launch_expand(d_pages, d_tile_page, static_cast<uint32_t>(tiles), ctx->d_resume.ptr, d_run_pos,
-                                   stream));
-    if (ctx->profiling) {
-        PQ2_HIP(ctx, hipEventRecord(stamp.e[2], stream));
-        ctx->stamps.push_back(stamp);
+    int32_t *d_status = static_cast<int32_t *>(ctx->d_status.ptr);
+
+    // with one round both kernels go to the caller's stream; with more, to the two internal streams, which
+    // fork from the caller's stream and join it again
+    hipStream_t ps = stream, es = stream;
+    if (rounds > 1) {
+        if (!ctx->parse_stream) {
+            PQ2_HIP(ctx, hipStreamCreateWithFlags(&ctx->parse_stream, hipStreamNonBlocking));
+            PQ2_HIP(ctx, hipStreamCreateWithFlags(&ctx->expand_stream, hipStreamNonBlocking));
+            for (hipEvent_t *e : {&ctx->fork, &ctx->parsed[0], &ctx->parsed[1], &ctx->parsed[2], &ctx->parsed[3],
+                                  &ctx->parse_joined, &ctx->expand_joined})
+                PQ2_HIP(ctx, hipEventCreateWithFlags(e, hipEventDisableTiming));
+        }
+        ps = ctx->parse_stream;
+        es = ctx->expand_stream;
+        PQ2_HIP(ctx, hipEventRecord(ctx->fork, stream));
+        PQ2_HIP(ctx, hipStreamWaitEvent(ps, ctx->fork, 0));
+        PQ2_HIP(ctx, hipStreamWaitEvent(es, ctx->fork, 0));
     }
+    auto stamped = [&](bool expand, hipStream_t on, auto &&launch) -> int32_t {
+        pq2_ctx::Stamp stamp{nullptr, nullptr, expand};
+        if (ctx->profiling) {
+            PQ2_HIP(ctx, hipEventCreate(&stamp.begin));
+            PQ2_HIP(ctx, hipEventCreate(&stamp.end));
+            PQ2_HIP(ctx, hipEventRecord(stamp.begin, on));
+        }
+        PQ2_HIP(ctx, launch());
+        if (ctx->profiling) {
+            PQ2_HIP(ctx, hipEventRecord(stamp.end, on));
+            ctx->stamps.push_back(stamp);
+        }
+        return PQ2_OK;
+    };
+    for (uint32_t r = 0; r < rounds; ++r) {
+        if ((st = stamped(false, ps, [&] {
+                 return pq2_launch_parse(d_pages, static_cast<uint32_t>(n_pages), ctx->d_resume.ptr, d_tile_page,
+                                         d_run_pos, d_status, ctx->d_state.ptr, r, ps);
+             })))
+            return st;
+        if (rounds > 1) {
+            PQ2_HIP(ctx, hipEventRecord(ctx->parsed[r], ps));
+            PQ2_HIP(ctx, hipStreamWaitEvent(es, ctx->parsed[r], 0));
+        }
+        if ((st = stamped(true, es, [&] {
+                 return pq2_launch_expand(d_pages, d_tile_page, static_cast<uint32_t>(round_start[r]),
+                                          static_cast<uint32_t>(round_start[r + 1] - round_start[r]),
+                                          ctx->d_resume.ptr, d_run_pos, r, es);
+             })))
+            return st;
+    }
+    if (rounds > 1) {
+        PQ2_HIP(ctx, hipEventRecord(ctx->parse_joined, ps));
+        PQ2_HIP(ctx, hipEventRecord(ctx->expand_joined, es));
+        PQ2_HIP(ctx, hipStreamWaitEvent(stream, ctx->parse_joined, 0));
+        PQ2_HIP(ctx, hipStreamWaitEvent(stream, ctx->expand_joined, 0));
+    }
+    if (ctx->profiling) ++ctx->stamped_batches;
     return PQ2_OK;
 }
 
@@ -226,6 +321,15 @@ int32_t pq2_ctx_create(int32_t device_id, pq2_ctx **out) {
     pq2_ctx *ctx = new (std::nothrow) pq2_ctx();
     if (!ctx) return PQ2_WOULD_OVER_ALLOCATE;
     ctx->device = device_id;
+    if (const char *v = std::getenv("PQ2_MIN_ROUNDED_TILES")) {
+        const long long t = std::atoll(v);
+        if (t > 0) ctx->min_rounded_tiles = static_cast<uint64_t>(t);
+    }
+    if (const char *v = std::getenv("PQ2_ROUND_SPLIT")) {
+        double a = 0, b = 0, c = 0;
+        if (std::sscanf(v, "%lf,%lf,%lf", &a, &b, &c) == 3 && 0 <= a && a <= b && b <= c && c <= 1)
+            ctx->round_split[0] = a, ctx->round_split[1] = b, ctx->round_split[2] = c;
+    }
     if (hipEventCreateWithFlags(&ctx->meta_copied, hipEventDisableTiming) != hipSuccess) {
         delete ctx;
         return PQ2_DEVICE_ERROR;
@@ -238,13 +342,20 @@ int32_t pq2_ctx_destroy(pq2_ctx *ctx) {
     if (!ctx) return PQ2_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    for (DevBuf *b : {&ctx->d_meta, &ctx->d_status, &ctx->d_resume, &ctx->d_tile_page, &ctx->d_run_pos, &ctx->d_in,
-                      &ctx->d_out})
+    for (DevBuf *b : {&ctx->d_meta, &ctx->d_status, &ctx->d_resume, &ctx->d_tile_page, &ctx->d_run_pos, &ctx->d_state,
+                      &ctx->d_in, &ctx->d_out})
         if (b->ptr) (void)hipFree(b->ptr);
+    for (hipStream_t s : {ctx->parse_stream, ctx->expand_stream})
+        if (s) (void)hipStreamDestroy(s);
+    for (hipEvent_t e : {ctx->fork, ctx->parsed[0], ctx->parsed[1], ctx->parsed[2], ctx->parsed[3], ctx->parse_joined,
+                         ctx->expand_joined})
+        if (e) (void)hipEventDestroy(e);
     if (ctx->h_meta) (void)hipHostFree(ctx->h_meta);
     if (ctx->meta_copied) (void)hipEventDestroy(ctx->meta_copied);
-    for (auto &s : ctx->stamps)
-        for (auto &e : s.e) (void)hipEventDestroy(e);
+    for (auto &s : ctx->stamps) {
+        (void)hipEventDestroy(s.begin);
+        (void)hipEventDestroy(s.end);
+    }
     for (int i = 0; i < 3; ++i) {
         if (ctx->copy_streams[i]) (void)hipStreamDestroy(ctx->copy_streams[i]);
         if (ctx->chunk_done[i]) (void)hipEventDestroy(ctx->chunk_done[i]);
@@ -274,21 +385,29 @@ int32_t pq2_ctx_enable_profiling(pq2_ctx *ctx, int32_t on) {
     return PQ2_OK;
 }
 
-int32_t pq2_ctx_kernel_times(pq2_ctx *ctx, double *parse_ms, double *expand_ms, uint64_t *batches) {
+int32_t pq2_ctx_kernel_times(pq2_ctx *ctx, double *parse_ms, double *expand_ms, uint64_t *batches,
+                             uint64_t *expand_launches) {
     if (!ctx || !parse_ms || !expand_ms || !batches) return PQ2_INVALID_PARAMETER;
     PQ2_HIP(ctx, hipSetDevice(ctx->device));
     *parse_ms = *expand_ms = 0.0;
-    *batches = ctx->stamps.size();
+    *batches = ctx->stamped_batches;
+    uint64_t launches = 0;
     for (auto &s : ctx->stamps) {
-        PQ2_HIP(ctx, hipEventSynchronize(s.e[2]));
-        float a = 0.f, b = 0.f;
-        PQ2_HIP(ctx, hipEventElapsedTime(&a, s.e[0], s.e[1]));
-        PQ2_HIP(ctx, hipEventElapsedTime(&b, s.e[1], s.e[2]));
-        *parse_ms += a;
-        *expand_ms += b;
-        for (auto &e : s.e) (void)hipEventDestroy(e);
+        PQ2_HIP(ctx, hipEventSynchronize(s.end));
+        float ms = 0.f;
+        PQ2_HIP(ctx, hipEventElapsedTime(&ms, s.begin, s.end));
+        if (s.expand) {
+            *expand_ms += ms;
+            ++launches;
+        } else {
+            *parse_ms += ms;
+        }
+        (void)hipEventDestroy(s.begin);
+        (void)hipEventDestroy(s.end);
     }
+    if (expand_launches) *expand_launches = launches;
     ctx->stamps.clear();
+    ctx->stamped_batches = 0;
     return PQ2_OK;
 }
 

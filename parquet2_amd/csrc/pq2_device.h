@@ -21,15 +21,56 @@ constexpr uint32_t kBlocksPerTile = 4;     // one 256-thread workgroup = 4 wave-
 constexpr uint32_t kTileValues = kBlockValues * kBlocksPerTile;
 constexpr uint32_t kEndPos = 0xffffffffu;  // resume position meaning "stream exhausted: zeros"
 
-// Device-side page descriptor (40 bytes), built by the host from pq2_page_desc.
+// A batch is decoded in up to kRounds rounds so that finding the headers of
+// one part of every page (parse_kernel) overlaps with producing the values of
+// the part before it (expand_kernel, on another stream).  Round r of a page
+// covers its tiles [round_tile[r], round_tile[r + 1]) (round_tile[0] = 0, the
+// last round ends with the page); tiles are numbered round-major over the
+// batch (all tiles of round 0 of all pages, then round 1, ...), so that the
+// tiles of one round form one contiguous grid.
+constexpr uint32_t kRounds = 4;
+
+// Device-side page descriptor (72 bytes), built by the host from pq2_page_desc.
 struct PageDev {
-    uint64_t in_addr;     // device address of the first stream byte
-    uint64_t out_addr;    // device address of the page's first output value
-    uint64_t run_base;    // index of the page's first entry in the header-position list
-    uint32_t in_len;      // stream bytes
-    uint32_t num_values;  // values to produce (0 if the page is skipped)
-    uint32_t num_bits;    // 0..32
-    uint32_t tile_base;   // index of the page's first tile (tile = 4096 values)
+    uint64_t in_addr;             // device address of the first stream byte
+    uint64_t out_addr;            // device address of the page's first output value
+    uint64_t run_base;            // index of the page's first entry in the header-position list
+    uint32_t in_len;              // stream bytes
+    uint32_t num_values;          // values to produce (0 if the page is skipped)
+    uint32_t num_bits;            // 0..32
+    uint32_t round_tile[kRounds];  // the page's first tile of round r (tile = 4096 values); [0] = 0, ascending
+    uint32_t tile_base[kRounds];   // batch-wide number of that tile
+    uint32_t reserved;
+
+    // The members are only ever indexed with constants: a register-resident copy of the descriptor stays in
+    // (scalar) registers.
+    static_assert(kRounds == 4, "the accessors spell out four rounds");
+    __device__ __forceinline__ uint32_t round_first(uint32_t r) const {
+        return r == 0 ? round_tile[0] : r == 1 ? round_tile[1] : r == 2 ? round_tile[2] : round_tile[3];
+    }
+    __device__ __forceinline__ uint32_t round_base(uint32_t r) const {
+        return r == 0 ? tile_base[0] : r == 1 ? tile_base[1] : r == 2 ? tile_base[2] : tile_base[3];
+    }
+    // batch-wide number of the page's tile t
+    __device__ __forceinline__ uint32_t tile_number(uint32_t t) const {
+        // the step of the numbering at each round boundary (wave-uniform), added where t lies beyond it
+        const uint32_t s1 = tile_base[1] - tile_base[0] - (round_tile[1] - round_tile[0]);
+        const uint32_t s2 = tile_base[2] - tile_base[1] - (round_tile[2] - round_tile[1]);
+        const uint32_t s3 = tile_base[3] - tile_base[2] - (round_tile[3] - round_tile[2]);
+        uint32_t number = tile_base[0] + t;
+        number += t >= round_tile[1] ? s1 : 0u;
+        number += t >= round_tile[2] ? s2 : 0u;
+        number += t >= round_tile[3] ? s3 : 0u;
+        return number;
+    }
+};
+
+// What parse_kernel keeps of a page between two rounds.
+struct ParseState {
+    uint32_t pos;       // a-offset of the next header
+    uint32_t produced;  // values the listed runs yield so far
+    uint32_t n_runs;    // entries of the header-position list so far
+    uint32_t done;      // the page's Resume entries and header list are complete
 };
 
 // The header-position list: for every page, the a-offsets of the headers of

@@ -61,7 +61,8 @@ constexpr uint32_t kExplicit = 0x8080u;  // `lo` of a parked record that carries
 
 __global__ __launch_bounds__(64) void parse_kernel(const PageDev *__restrict__ pages, uint32_t n_pages,
                                                    Resume *__restrict__ resume, uint32_t *__restrict__ tile_page,
-                                                   uint32_t *__restrict__ run_pos, int32_t *__restrict__ status) {
+                                                   uint32_t *__restrict__ run_pos, int32_t *__restrict__ status,
+                                                   ParseState *__restrict__ state, uint32_t round) {
     // win[a - win_lo] holds stream byte a for a in [win_lo, win_lo + kWin)
     __shared__ __attribute__((aligned(16))) uint8_t win[kWin];
 
@@ -71,19 +72,39 @@ __global__ __launch_bounds__(64) void parse_kernel(const PageDev *__restrict__ p
     const PageDev pg = pages[page];
     const uint32_t n = pg.num_values;
     if (n == 0) {
-        if (lane == 0) status[page] = 0;
+        if (lane == 0 && round == 0) status[page] = 0;
         return;
     }
     const uint32_t w = pg.num_bits;
     const uint32_t n_blocks = (n + kBlockValues - 1) / kBlockValues;
-    Resume *const entries = resume + (size_t)pg.tile_base * kBlocksPerTile;
+    // the Resume entry of the page's block b
+    auto entry = [&](uint32_t b) -> Resume * {
+        return resume + (size_t)pg.tile_number(b / kBlocksPerTile) * kBlocksPerTile + (b % kBlocksPerTile);
+    };
     // expand_kernel finds its page through tile_page[tile]
-    for (uint32_t t = lane; t < (n_blocks + kBlocksPerTile - 1) / kBlocksPerTile; t += 64)
-        tile_page[pg.tile_base + t] = page;
+    if (round == 0)
+        for (uint32_t t = lane; t < (n_blocks + kBlocksPerTile - 1) / kBlocksPerTile; t += 64)
+            tile_page[pg.tile_number(t)] = page;
+
+    const uint32_t delta = (uint32_t)(pg.in_addr & 15u);
+    ParseState ps;
+    if (round == 0) {
+        ps.pos = delta, ps.produced = 0, ps.n_runs = 0, ps.done = 0;
+    } else {
+        ps = state[page];  // the same for every lane: into scalar registers
+        ps.pos = __builtin_amdgcn_readfirstlane(ps.pos);
+        ps.produced = __builtin_amdgcn_readfirstlane(ps.produced);
+        ps.n_runs = __builtin_amdgcn_readfirstlane(ps.n_runs);
+        ps.done = __builtin_amdgcn_readfirstlane(ps.done);
+        if (ps.done) return;
+    }
+    // this round ends once the values of the page's tiles up to the round's last one are covered
+    const uint64_t round_end = round + 1u < kRounds ? (uint64_t)pg.round_first(round + 1u) * kTileValues : n;
+    const uint32_t target = round_end > n ? n : (uint32_t)round_end;
 
     uint32_t *const hdrs = run_pos + pg.run_base;  // header positions of the runs that yield values
-    uint32_t n_runs = 0;                           // entries of `hdrs` written so far
-    uint32_t produced = 0;                         // values those runs yield
+    uint32_t n_runs = ps.n_runs;                   // entries of `hdrs` written so far
+    uint32_t produced = ps.produced;               // values those runs yield
 
     // blocks [from, n_blocks): the stream is exhausted, zeros follow (mod.rs:95); closes the header list
     auto fill_end = [&](uint32_t from) {
@@ -92,17 +113,22 @@ __global__ __launch_bounds__(64) void parse_kernel(const PageDev *__restrict__ p
         e.rem_kind = kRemMask | (kRle << 31);
         e.payload = 0;
         e.skip = 0;
-        for (uint32_t b = from + lane; b < n_blocks; b += 64) entries[b] = e;
+        for (uint32_t b = from + lane; b < n_blocks; b += 64) *entry(b) = e;
         if (lane == 0) hdrs[n_runs] = kEndPos;
+    };
+    auto finish = [&](int32_t st) {
+        fill_end((produced + kBlockValues - 1u) / kBlockValues);
+        if (lane == 0) {
+            status[page] = st;
+            state[page].done = 1u;
+        }
     };
 
     if (w == 0 || pg.in_len == 0 || w > 32) {  // decoder.rs:31-37: nothing to iterate
-        fill_end(0);
-        if (lane == 0) status[page] = 0;
+        finish(0);
         return;
     }
 
-    const uint32_t delta = (uint32_t)(pg.in_addr & 15u);
     const uint64_t base16 = pg.in_addr - delta;
     const uint32_t end = delta + pg.in_len;  // a-offset one past the last stream byte
     const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(base16, (end + 3u) & ~3u);
@@ -110,8 +136,8 @@ __global__ __launch_bounds__(64) void parse_kernel(const PageDev *__restrict__ p
     const uint32_t rb_mask = rb < 4 ? (1u << (rb * 8u)) - 1u : ~0u;  // the first min(4, rb) of them
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)win;
 
-    u32x4 pre[4];         // prefetched half [win_lo + kWin, win_lo + kWin + kHalf)
-    uint32_t win_lo = 0;  // a-offset (multiple of kHalf) of the first resident byte
+    u32x4 pre[4];                              // prefetched half [win_lo + kWin, win_lo + kWin + kHalf)
+    uint32_t win_lo = ps.pos & ~(kHalf - 1u);  // a-offset (multiple of kHalf) of the first resident byte
 
     auto load_half = [&](uint32_t half_a, u32x4 *r) {
 #pragma unroll
@@ -152,16 +178,15 @@ __global__ __launch_bounds__(64) void parse_kernel(const PageDev *__restrict__ p
 
     {  // first window
         u32x4 a[4], b[4];
-        load_half(0, a);
-        load_half(kHalf, b);
-        load_half(kWin, pre);
+        load_half(win_lo, a);
+        load_half(win_lo + kHalf, b);
+        load_half(win_lo + kWin, pre);
         store_half(0, a);
         store_half(kHalf, b);
         __syncthreads();
     }
 
-    uint32_t pos = delta;  // a-offset of the next header
-    int32_t st = 0;
+    uint32_t pos = ps.pos;  // a-offset of the next header
     for (;;) {
         // ---- chase: park up to 64 runs, record i in lane i --------------------------------------------
         uint32_t r_pos = 0, r_lo = 0, r_hi = 0, r_info = 0;
@@ -170,17 +195,24 @@ __global__ __launch_bounds__(64) void parse_kernel(const PageDev *__restrict__ p
         for (;;) {
             // Runs whose header has one or two bytes (uleb128.rs:3-23) and which lie inside the stream
             // (decoder.rs:44-63): next = pos + header bytes + (bit-packed ? (header >> 1) * w : ceil8(w)).
-            // why: 0 = 64 records parked; 1 = the header at pos is not of that kind (nothing parked for it);
-            // 2 = a record was parked but the next header's 8 bytes are not all in the window.
-            uint32_t why, lo, hi, groups, t, bytes, nm1, addr;  // nm1: the next header's position minus one
+            // The loop runs with lane 0 alone enabled: an LDS read that is not naturally aligned is replayed
+            // per enabled lane, and v_readfirstlane / v_writelane do not need the other lanes.  It has one
+            // branch: every reason to stop is folded into `chk` (a header of three or more bytes, a run that
+            // passes the end of the stream, a next header whose 8 bytes are not all in the window, the 64th
+            // record).  Each pass parks its record before it knows whether the record counts; `m` is kept
+            // minus 64 inside so that the 64th increment sets the carry.
+            uint32_t lo, hi, groups, t, bytes, nm1, chk, addr;  // nm1: the next header's position minus one
+            uint64_t exec_all;
             const uint32_t voff = lds_base - win_lo;
             asm volatile(
+                "s_mov_b64 %[exec_all], exec\n\t"
+                "s_mov_b64 exec, 1\n\t"
+                "s_sub_u32 %[m], %[m], 64\n\t"
                 "v_add_u32 %[addr], %[pos], %[voff]\n\t"
                 "ds_read_b64 v[2:3], %[addr]\n"
                 "1:\n\t"
                 "s_waitcnt lgkmcnt(0)\n\t"
                 "v_readfirstlane_b32 %[lo], v2\n\t"
-                "v_readfirstlane_b32 %[hi], v3\n\t"
                 "s_bfe_u32 %[groups], %[lo], 0x60001\n\t"
                 "s_lshr_b32 %[t], %[lo], 2\n\t"
                 "s_and_b32 %[t], %[t], 0x1fc0\n\t"
@@ -192,40 +224,34 @@ __global__ __launch_bounds__(64) void parse_kernel(const PageDev *__restrict__ p
                 "s_cselect_b32 %[bytes], %[bytes], %[rb]\n\t"
                 "s_bitcmp1_b32 %[lo], 7\n\t"
                 "s_addc_u32 %[nm1], %[pos], %[bytes]\n\t"
+                "v_readfirstlane_b32 %[hi], v3\n\t"
                 "v_add_u32 %[addr], %[nm1], %[voff1]\n\t"
                 "ds_read_b64 v[2:3], %[addr]\n\t"
-                "s_andn2_b32 %[t], 0x8080, %[lo]\n\t"
-                "s_cbranch_scc0 2f\n\t"
-                "s_cmp_gt_u32 %[nm1], %[end_m1]\n\t"
-                "s_cbranch_scc1 2f\n\t"
                 "s_mov_b32 m0, %[m]\n\t"
                 "v_writelane_b32 %[r_pos], %[pos], m0\n\t"
                 "v_writelane_b32 %[r_lo], %[lo], m0\n\t"
                 "v_writelane_b32 %[r_hi], %[hi], m0\n\t"
-                "s_add_u32 %[m], %[m], 1\n\t"
                 "s_add_u32 %[pos], %[nm1], 1\n\t"
-                "s_cmp_gt_u32 %[nm1], %[lim_m1]\n\t"
-                "s_cbranch_scc1 3f\n\t"
-                "s_cmp_lt_u32 %[m], 64\n\t"
+                "s_andn2_b32 %[t], 0x8080, %[lo]\n\t"
+                "s_cselect_b32 %[chk], %[nm1], -1\n\t"
+                "s_add_u32 %[m], %[m], 1\n\t"
+                "s_cselect_b32 %[chk], -1, %[chk]\n\t"
+                "s_cmp_le_u32 %[chk], %[limit]\n\t"
                 "s_cbranch_scc1 1b\n\t"
-                "s_mov_b32 %[why], 0\n\t"
-                "s_branch 4f\n"
-                "2:\n\t"
-                "s_mov_b32 %[why], 1\n\t"
-                "s_branch 4f\n"
-                "3:\n\t"
-                "s_mov_b32 %[why], 2\n"
-                "4:\n\t"
-                "s_waitcnt lgkmcnt(0)"
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "s_mov_b64 exec, %[exec_all]\n\t"
+                "s_add_u32 %[m], %[m], 64"
                 : [pos] "+s"(pos), [m] "+s"(m), [r_pos] "+v"(r_pos), [r_lo] "+v"(r_lo), [r_hi] "+v"(r_hi),
-                  [why] "=&s"(why), [lo] "=&s"(lo), [hi] "=&s"(hi), [groups] "=&s"(groups), [t] "=&s"(t),
-                  [bytes] "=&s"(bytes), [nm1] "=&s"(nm1), [addr] "=&v"(addr)
-                : [w] "s"(w), [rb] "s"(rb), [end_m1] "s"(end - 1u), [lim_m1] "s"(win_lo + kWin - 9u), [voff] "v"(voff),
+                  [lo] "=&s"(lo), [hi] "=&s"(hi), [groups] "=&s"(groups), [t] "=&s"(t), [bytes] "=&s"(bytes),
+                  [nm1] "=&s"(nm1), [chk] "=&s"(chk), [addr] "=&v"(addr), [exec_all] "=&s"(exec_all)
+                : [w] "s"(w), [rb] "s"(rb), [limit] "s"(min(end - 1u, win_lo + kWin - 9u)), [voff] "v"(voff),
                   [voff1] "v"(voff + 1u)
                 : "v2", "v3", "scc", "memory");
-            if (why == 0u) break;
-            if (why == 1u) {
-                // three or more header bytes, a run cut by the end of the stream, or the end itself
+            if ((~lo & kExplicit) == 0u || nm1 > end - 1u) {
+                // three or more header bytes, a run cut by the end of the stream, or the end itself: the record
+                // parked last does not count
+                --m;
+                pos = __builtin_amdgcn_readlane(r_pos, m);
                 if (!resident(pos, 32u)) slide(pos);
                 const RunInfo run = decode_run(rd, pos, end, w, 0xffffffffu);
                 const uint32_t e_lo = kExplicit | (run.kind << 16);
@@ -297,7 +323,7 @@ __global__ __launch_bounds__(64) void parse_kernel(const PageDev *__restrict__ p
                 e.rem_kind = (run_eff - skip) | (run_kind << 31);
                 e.payload = run_info;
                 e.skip = skip;
-                entries[b] = e;
+                *entry(b) = e;
             }
         };
         if (nb != 0u && nb <= 4u) write_entries(b_first, 1u, b_last, idx, first, eff, kind, info);
@@ -310,14 +336,21 @@ __global__ __launch_bounds__(64) void parse_kernel(const PageDev *__restrict__ p
         }
         n_runs += (uint32_t)__popcll(ymask);
         produced += __builtin_amdgcn_readlane(incl, 63);
-        if (produced >= n) break;
-        if (term != 0u) {
-            if (term == kPanic) st = 5;  // PQ2_REFERENCE_WOULD_PANIC
-            break;
+        if (produced >= n) {
+            finish(0);
+            return;
         }
+        if (term != 0u) {
+            finish(term == kPanic ? 5 : 0);  // PQ2_REFERENCE_WOULD_PANIC | the stream is exhausted
+            return;
+        }
+        if (produced >= target) break;
     }
-    fill_end((produced + kBlockValues - 1u) / kBlockValues);
-    if (lane == 0) status[page] = st;
+    if (lane == 0) {
+        ParseState out;
+        out.pos = pos, out.produced = produced, out.n_runs = n_runs, out.done = 0;
+        state[page] = out;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -469,17 +502,18 @@ __device__ __forceinline__ void expand_block(const __amdgpu_buffer_rsrc_t rsrc, 
 __global__ __launch_bounds__(256, PQ2_EXPAND_WAVES) void expand_kernel(const PageDev *__restrict__ pages,
                                                        const uint32_t *__restrict__ tile_page,
                                                        const Resume *__restrict__ resume,
-                                                       const uint32_t *__restrict__ run_pos) {
+                                                       const uint32_t *__restrict__ run_pos,
+                                                       uint32_t tile_start, uint32_t round) {
     __shared__ __attribute__((aligned(16))) uint8_t stage[kBlocksPerTile * kWinBytes];
     __shared__ __attribute__((aligned(16))) uint2 table[kBlocksPerTile * (kTableRuns + 2)];
 
-    const uint32_t tile = blockIdx.x;
+    const uint32_t tile = tile_start + blockIdx.x;  // batch-wide tile number; the tiles of one round are contiguous
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
 
     const PageDev pg = pages[tile_page[tile]];
     const uint32_t n = pg.num_values;
-    const uint32_t block = (tile - pg.tile_base) * kBlocksPerTile + wave;
+    const uint32_t block = (pg.round_first(round) + (tile - pg.round_base(round))) * kBlocksPerTile + wave;
     const uint32_t block_start = block * kBlockValues;
     if (block_start >= n) return;
     const uint32_t block_n = min(kBlockValues, n - block_start);
@@ -548,18 +582,21 @@ __global__ __launch_bounds__(256) void bitunpack_kernel(uint64_t in_addr, uint32
 
 // ---- launchers (called from pq2_api.cpp) ----------------------------------------
 extern "C" hipError_t pq2_launch_parse(const void *pages, uint32_t n_pages, void *resume, uint32_t *tile_page,
-                                       uint32_t *run_pos, int32_t *status, hipStream_t stream) {
+                                       uint32_t *run_pos, int32_t *status, void *state, uint32_t round,
+                                       hipStream_t stream) {
     if (n_pages == 0) return hipSuccess;
     hipLaunchKernelGGL(pq2::parse_kernel, dim3(n_pages), dim3(64), 0, stream, (const pq2::PageDev *)pages, n_pages,
-                       (pq2::Resume *)resume, tile_page, run_pos, status);
+                       (pq2::Resume *)resume, tile_page, run_pos, status, (pq2::ParseState *)state, round);
     return hipGetLastError();
 }
 
-extern "C" hipError_t pq2_launch_expand(const void *pages, const uint32_t *tile_page, uint32_t n_tiles,
-                                        const void *resume, const uint32_t *run_pos, hipStream_t stream) {
+// the tiles [tile_start, tile_start + n_tiles) are those of round `round`
+extern "C" hipError_t pq2_launch_expand(const void *pages, const uint32_t *tile_page, uint32_t tile_start,
+                                        uint32_t n_tiles, const void *resume, const uint32_t *run_pos, uint32_t round,
+                                        hipStream_t stream) {
     if (n_tiles == 0) return hipSuccess;
     hipLaunchKernelGGL(pq2::expand_kernel, dim3(n_tiles), dim3(256), 0, stream, (const pq2::PageDev *)pages,
-                       tile_page, (const pq2::Resume *)resume, run_pos);
+                       tile_page, (const pq2::Resume *)resume, run_pos, tile_start, round);
     return hipGetLastError();
 }
 

@@ -9,11 +9,22 @@ from parquet2_amd._lib import INVALID_PARAMETER, OK, REFERENCE_WOULD_PANIC
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def ctx():
+@pytest.fixture(scope="module", params=["one_round", "four_rounds"])
+def ctx(request):
+    """Every test runs twice: with the batch decoded in one round (what batches of this size get), and with
+    the round pipeline forced on (parse of part r + 1 on one stream while part r is expanded on another), which
+    only large batches use by default.  The context reads the two knobs when it is created."""
+    import os
+
     from parquet2_amd import Context
 
-    c = Context(0)
+    knobs = {"PQ2_MIN_ROUNDED_TILES": "1", "PQ2_ROUND_SPLIT": "0.1,0.3,0.6"} if request.param == "four_rounds" else {}
+    os.environ.update(knobs)
+    try:
+        c = Context(0)
+    finally:
+        for k in knobs:
+            del os.environ[k]
     yield c
     c.close()
 

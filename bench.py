@@ -41,6 +41,8 @@ def parse_args():
     ap.add_argument("--distinct", type=int, default=16, help="distinct generated pages (replicated on the device)")
     ap.add_argument("--workload", default="dict", choices=["dict", "def", "adversarial", "bitpacked"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true",
+                    help="skip the parity gate (only for timing experiments with builds that write no results)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     return ap.parse_args()
 
@@ -173,16 +175,17 @@ def main():
                                        want_status=want_status)
 
     # ---- parity gate: every page of the batch must equal the generator's values ------------------------
-    status = step(want_status=True)
-    assert (status == 0).all(), "non-OK page status"
-    out2d = d_out.view(my_pages, n)
-    for i in range(min(my_pages, len(pages))):
-        expect = torch.from_numpy(pages[(lo + i) % len(pages)][1].view(np.int32)).to(dev)
-        assert torch.equal(out2d[i], expect), "GPU output differs from the expected values on page %d" % i
-    for i in range(len(pages), my_pages):
-        if i % 61 == 0 or i == my_pages - 1:
-            assert torch.equal(out2d[i], out2d[i % len(pages)]), "replica %d differs" % i
-    del expect
+    if not args.no_parity:  # kernel-timing experiments with builds that do not write results
+        status = step(want_status=True)
+        assert (status == 0).all(), "non-OK page status"
+        out2d = d_out.view(my_pages, n)
+        for i in range(min(my_pages, len(pages))):
+            expect = torch.from_numpy(pages[(lo + i) % len(pages)][1].view(np.int32)).to(dev)
+            assert torch.equal(out2d[i], expect), "GPU output differs from the expected values on page %d" % i
+        for i in range(len(pages), my_pages):
+            if i % 61 == 0 or i == my_pages - 1:
+                assert torch.equal(out2d[i], out2d[i % len(pages)]), "replica %d differs" % i
+        expect = None
 
     for _ in range(args.warmup):
         step()

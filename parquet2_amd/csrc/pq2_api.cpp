@@ -71,9 +71,11 @@ struct pq2_ctx {
     double round_split[kRounds - 1] = {0.25, 1.0, 1.0};
     uint64_t min_rounded_tiles = kMinRoundedTiles;
     // rounds: parse_kernel of round r + 1 runs on parse_stream while expand_kernel of round r runs on expand_stream
-    hipStream_t parse_stream = nullptr, expand_stream = nullptr;
+    // (two of them, taken in turn: the expand launches of one batch do not depend on each other, so the next one
+    // starts while the last waves of the previous one drain)
+    hipStream_t parse_stream = nullptr, expand_stream[2] = {nullptr, nullptr};
     hipEvent_t fork = nullptr, parsed[4] = {nullptr, nullptr, nullptr, nullptr}, parse_joined = nullptr,
-               expand_joined = nullptr;
+               expand_joined[2] = {nullptr, nullptr};
     std::vector<int32_t> host_status;  // statuses decided on the host (bad num_bits)
     uint64_t last_n_pages = 0;
     hipStream_t last_stream = nullptr;
@@ -240,20 +242,23 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
 
     // with one round both kernels go to the caller's stream; with more, to the two internal streams, which
     // fork from the caller's stream and join it again
-    hipStream_t ps = stream, es = stream;
+    hipStream_t ps = stream, es[2] = {stream, stream};
     if (rounds > 1) {
         if (!ctx->parse_stream) {
             PQ2_HIP(ctx, hipStreamCreateWithFlags(&ctx->parse_stream, hipStreamNonBlocking));
-            PQ2_HIP(ctx, hipStreamCreateWithFlags(&ctx->expand_stream, hipStreamNonBlocking));
+            PQ2_HIP(ctx, hipStreamCreateWithFlags(&ctx->expand_stream[0], hipStreamNonBlocking));
+            PQ2_HIP(ctx, hipStreamCreateWithFlags(&ctx->expand_stream[1], hipStreamNonBlocking));
             for (hipEvent_t *e : {&ctx->fork, &ctx->parsed[0], &ctx->parsed[1], &ctx->parsed[2], &ctx->parsed[3],
-                                  &ctx->parse_joined, &ctx->expand_joined})
+                                  &ctx->parse_joined, &ctx->expand_joined[0], &ctx->expand_joined[1]})
                 PQ2_HIP(ctx, hipEventCreateWithFlags(e, hipEventDisableTiming));
         }
         ps = ctx->parse_stream;
-        es = ctx->expand_stream;
+        es[0] = ctx->expand_stream[0];
+        es[1] = ctx->expand_stream[1];
         PQ2_HIP(ctx, hipEventRecord(ctx->fork, stream));
         PQ2_HIP(ctx, hipStreamWaitEvent(ps, ctx->fork, 0));
-        PQ2_HIP(ctx, hipStreamWaitEvent(es, ctx->fork, 0));
+        PQ2_HIP(ctx, hipStreamWaitEvent(es[0], ctx->fork, 0));
+        PQ2_HIP(ctx, hipStreamWaitEvent(es[1], ctx->fork, 0));
     }
     auto stamped = [&](bool expand, hipStream_t on, auto &&launch) -> int32_t {
         pq2_ctx::Stamp stamp{nullptr, nullptr, expand};
@@ -277,20 +282,22 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
             return st;
         if (rounds > 1) {
             PQ2_HIP(ctx, hipEventRecord(ctx->parsed[r], ps));
-            PQ2_HIP(ctx, hipStreamWaitEvent(es, ctx->parsed[r], 0));
+            PQ2_HIP(ctx, hipStreamWaitEvent(es[r & 1u], ctx->parsed[r], 0));
         }
-        if ((st = stamped(true, es, [&] {
+        if ((st = stamped(true, es[r & 1u], [&] {
                  return pq2_launch_expand(d_pages, d_tile_page, static_cast<uint32_t>(round_start[r]),
                                           static_cast<uint32_t>(round_start[r + 1] - round_start[r]),
-                                          ctx->d_resume.ptr, d_run_pos, r, es);
+                                          ctx->d_resume.ptr, d_run_pos, r, es[r & 1u]);
              })))
             return st;
     }
     if (rounds > 1) {
         PQ2_HIP(ctx, hipEventRecord(ctx->parse_joined, ps));
-        PQ2_HIP(ctx, hipEventRecord(ctx->expand_joined, es));
         PQ2_HIP(ctx, hipStreamWaitEvent(stream, ctx->parse_joined, 0));
-        PQ2_HIP(ctx, hipStreamWaitEvent(stream, ctx->expand_joined, 0));
+        for (int i = 0; i < 2; ++i) {
+            PQ2_HIP(ctx, hipEventRecord(ctx->expand_joined[i], es[i]));
+            PQ2_HIP(ctx, hipStreamWaitEvent(stream, ctx->expand_joined[i], 0));
+        }
     }
     if (ctx->profiling) ++ctx->stamped_batches;
     return PQ2_OK;
@@ -345,10 +352,10 @@ int32_t pq2_ctx_destroy(pq2_ctx *ctx) {
     for (DevBuf *b : {&ctx->d_meta, &ctx->d_status, &ctx->d_resume, &ctx->d_tile_page, &ctx->d_run_pos, &ctx->d_state,
                       &ctx->d_in, &ctx->d_out})
         if (b->ptr) (void)hipFree(b->ptr);
-    for (hipStream_t s : {ctx->parse_stream, ctx->expand_stream})
+    for (hipStream_t s : {ctx->parse_stream, ctx->expand_stream[0], ctx->expand_stream[1]})
         if (s) (void)hipStreamDestroy(s);
     for (hipEvent_t e : {ctx->fork, ctx->parsed[0], ctx->parsed[1], ctx->parsed[2], ctx->parsed[3], ctx->parse_joined,
-                         ctx->expand_joined})
+                         ctx->expand_joined[0], ctx->expand_joined[1]})
         if (e) (void)hipEventDestroy(e);
     if (ctx->h_meta) (void)hipHostFree(ctx->h_meta);
     if (ctx->meta_copied) (void)hipEventDestroy(ctx->meta_copied);

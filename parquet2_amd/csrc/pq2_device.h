@@ -15,6 +15,11 @@
 namespace pq2 {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// Output values live in global memory.  The address arrives as an integer inside a descriptor, so the pointer
+// type has to say it: a generic pointer would make every store a flat_store, which is also counted by the
+// LDS / scalar-memory counter and holds back the waits of LDS reads.
+typedef __attribute__((address_space(1))) uint32_t out_u32;
+typedef __attribute__((address_space(1))) u32x4 out_u32x4;
 
 constexpr uint32_t kBlockValues = 1024;    // values per wave-block (PQ2_BLOCK_VALUES)
 constexpr uint32_t kBlocksPerTile = 4;     // one 256-thread workgroup = 4 wave-blocks
@@ -86,7 +91,8 @@ struct Resume {
     uint32_t run_index;  // index of this run in the page's header-position list
     uint32_t rem_kind;   // values of the run from the block's first value on | kind << 31
     uint32_t payload;    // bit-packed: a-offset of the run's payload; RLE: the value
-    uint32_t skip;       // values of the run that precede the block
+    uint32_t skip;       // bit-packed: values of the run that precede the block; RLE: a-offset of the byte
+                         // behind the run (where the stream bytes the block may need begin), kEndPos if none
 };
 constexpr uint32_t kRemMask = 0x7fffffffu;
 
@@ -328,11 +334,13 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v, uint32_t lane
 
 // ---- stores -------------------------------------------------------------------
 
-__device__ __forceinline__ void store4(u32x4 v, uint32_t *p) {
-#ifdef PQ2_NT_STORES
-    __builtin_nontemporal_store(v, (u32x4 *)p);
+__device__ __forceinline__ void store4(u32x4 v, out_u32 *p) {
+#ifdef PQ2_EXPERIMENT_NO_STORES  // timing experiment only: results are not written
+    if (v.x == 0x12345678u && v.y == 0x9abcdef0u && v.z == 0x0fedcba9u) *(out_u32x4 *)p = v;
+#elif defined(PQ2_NT_STORES)
+    __builtin_nontemporal_store(v, (out_u32x4 *)p);
 #else
-    *(u32x4 *)p = v;
+    *(out_u32x4 *)p = v;
 #endif
 }
 
@@ -357,6 +365,17 @@ struct Window {
 #pragma unroll
         for (uint32_t i = 0; i < 4; ++i)
             if (i < pieces) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lo + i * 1024u + lane * 16u, 0, 0);
+#pragma unroll
+        for (uint32_t i = 0; i < 4; ++i)
+            if (i < pieces) *(u32x4 *)(lds + i * 1024u + lane * 16u) = v[i];
+        hi = lo + pieces * 1024u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    // the window takes over `pieces` KiB fetched earlier into registers (lane L of piece i: bytes
+    // [from16 + i * 1024 + L * 16, + 16))
+    __device__ __forceinline__ void put(const u32x4 *v, uint32_t from16, uint32_t pieces, uint32_t lane) {
+        lo = from16;
 #pragma unroll
         for (uint32_t i = 0; i < 4; ++i)
             if (i < pieces) *(u32x4 *)(lds + i * 1024u + lane * 16u) = v[i];
@@ -422,7 +441,7 @@ __device__ __forceinline__ uint32_t extract1(__amdgpu_buffer_rsrc_t rsrc, uint32
 
 template <int W>
 __device__ __forceinline__ void emit_bp(__amdgpu_buffer_rsrc_t rsrc, uint32_t payload, uint32_t v_begin,
-                                        uint32_t *out, uint32_t count, uint32_t lane) {
+                                        out_u32 *out, uint32_t count, uint32_t lane) {
     const uint32_t head = (4u - (uint32_t)(((uintptr_t)out >> 2) & 3u)) & 3u;
     const uint32_t h = head < count ? head : count;
     if (lane < h) out[lane] = extract1(rsrc, payload, v_begin + lane, W);
@@ -434,7 +453,7 @@ __device__ __forceinline__ void emit_bp(__amdgpu_buffer_rsrc_t rsrc, uint32_t pa
 }
 
 __device__ __forceinline__ void emit_bp_dispatch(uint32_t w, __amdgpu_buffer_rsrc_t rsrc, uint32_t payload,
-                                                 uint32_t v_begin, uint32_t *out, uint32_t count, uint32_t lane) {
+                                                 uint32_t v_begin, out_u32 *out, uint32_t count, uint32_t lane) {
     switch (w) {
 #define PQ2_W(N)                                             \
     case N:                                                  \

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(64) void parse_kernel(const PageDev *__restrict__ p
         e.run_index = n_runs;
         e.rem_kind = kRemMask | (kRle << 31);
         e.payload = 0;
-        e.skip = 0;
+        e.skip = kEndPos;
         for (uint32_t b = from + lane; b < n_blocks; b += 64) *entry(b) = e;
         if (lane == 0) hdrs[n_runs] = kEndPos;
     };
@@ -254,7 +254,8 @@ __global__ __launch_bounds__(64) void parse_kernel(const PageDev *__restrict__ p
                 pos = __builtin_amdgcn_readlane(r_pos, m);
                 if (!resident(pos, 32u)) slide(pos);
                 const RunInfo run = decode_run(rd, pos, end, w, 0xffffffffu);
-                const uint32_t e_lo = kExplicit | (run.kind << 16);
+                // bits 16..17: kind; bits 20..27: header + value bytes of an RLE run
+                const uint32_t e_lo = kExplicit | (run.kind << 16) | (((run.next - pos) & 0xffu) << 20);
                 const uint32_t e_hi = __builtin_amdgcn_readfirstlane(run.count);
                 const uint32_t e_info = __builtin_amdgcn_readfirstlane(run.kind == kRle ? run.value : run.payload);
                 // v_writelane_b32 ignores EXEC; it may read one scalar register only, so the lane goes through M0
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(64) void parse_kernel(const PageDev *__restrict__ p
         }
 
         // ---- place: lane i decodes record i; a prefix sum over the run lengths places the runs -------------
-        uint32_t kind, count, info;
+        uint32_t kind, count, info, after;  // after: a-offset of the byte behind an RLE run
         {
             const uint32_t two = (r_lo >> 7) & 1u;
             const uint32_t groups = ((r_lo >> 1) & 0x3fu) | (two ? (r_lo >> 2) & 0x1fc0u : 0u);
@@ -287,11 +288,13 @@ __global__ __launch_bounds__(64) void parse_kernel(const PageDev *__restrict__ p
             kind = (r_lo & 1u) ^ 1u;
             count = kind == kRle ? groups : groups * 8u;         // mod.rs:41-64
             info = kind == kRle ? (rest & rb_mask) : r_pos + 1u + two;  // RLE value (not masked to w) | payload
+            after = r_pos + 1u + two + rb;
         }
         if ((~r_lo & kExplicit) == 0u) {
             kind = (r_lo >> 16) & 3u;
             count = r_hi;
             info = r_info;
+            after = r_pos + ((r_lo >> 20) & 0xffu);
         }
         const uint32_t left = n - produced;  // > 0
         const uint32_t cnt = (lane < m && kind < kEnd) ? min(count, left) : 0u;
@@ -315,24 +318,25 @@ __global__ __launch_bounds__(64) void parse_kernel(const PageDev *__restrict__ p
         const uint32_t b_last = (first + eff - 1u) / kBlockValues;  // meaningful where `yields`
         const uint32_t nb = (yields && b_last >= b_first) ? b_last - b_first + 1u : 0u;
         auto write_entries = [&](uint32_t b_from, uint32_t b_step, uint32_t b_to, uint32_t run_index,
-                                 uint32_t run_first, uint32_t run_eff, uint32_t run_kind, uint32_t run_info) {
+                                 uint32_t run_first, uint32_t run_eff, uint32_t run_kind, uint32_t run_info,
+                                 uint32_t run_after) {
             for (uint32_t b = b_from; b <= b_to; b += b_step) {
                 const uint32_t skip = b * kBlockValues - run_first;
                 Resume e;
                 e.run_index = run_index;
                 e.rem_kind = (run_eff - skip) | (run_kind << 31);
                 e.payload = run_info;
-                e.skip = skip;
+                e.skip = run_kind == kRle ? run_after : skip;
                 *entry(b) = e;
             }
         };
-        if (nb != 0u && nb <= 4u) write_entries(b_first, 1u, b_last, idx, first, eff, kind, info);
+        if (nb != 0u && nb <= 4u) write_entries(b_first, 1u, b_last, idx, first, eff, kind, info, after);
         for (uint64_t big = __ballot(nb > 4u); big != 0; big &= big - 1) {  // long runs: the whole wave writes
             const uint32_t l = (uint32_t)__builtin_ctzll(big);
             write_entries(__builtin_amdgcn_readlane(b_first, l) + lane, 64u, __builtin_amdgcn_readlane(b_last, l),
                           __builtin_amdgcn_readlane(idx, l), __builtin_amdgcn_readlane(first, l),
                           __builtin_amdgcn_readlane(eff, l), __builtin_amdgcn_readlane(kind, l),
-                          __builtin_amdgcn_readlane(info, l));
+                          __builtin_amdgcn_readlane(info, l), __builtin_amdgcn_readlane(after, l));
         }
         n_runs += (uint32_t)__popcll(ymask);
         produced += __builtin_amdgcn_readlane(incl, 63);
@@ -359,13 +363,46 @@ __global__ __launch_bounds__(64) void parse_kernel(const PageDev *__restrict__ p
 constexpr uint32_t kTableRuns = 64;      // run-table entries per wave (the last one stays a sentinel)
 constexpr uint32_t kNoRun = 0xffffffffu; // table key of an unused entry: compares greater than any position
 
+// The stream bytes and header positions a block starts from, requested from memory one block ahead of the
+// block's turn.
+struct Fetch {
+    u32x4 piece[4];   // lane L of piece i: stream bytes [from16 + i * 1024 + L * 16, + 16)
+    uint32_t hp;      // lane r < 63: position of header rs.run_index + 1 + r; kEndPos elsewhere
+    uint32_t from16;  // a-offset of the first byte (16-byte aligned)
+    uint32_t pieces;  // 0..4
+    Resume rs;        // where the block starts (wave-uniform)
+};
+
+__device__ __forceinline__ void fetch_block(Fetch &f, const __amdgpu_buffer_rsrc_t rsrc, const Resume rs,
+                                            const uint32_t *__restrict__ hdrs, const uint32_t w,
+                                            const uint32_t block_n, const uint32_t lane) {
+    const uint32_t kind = rs.rem_kind >> 31;
+    const bool alone = (rs.rem_kind & kRemMask) >= block_n;  // the first run covers the whole block
+    // bit-packed: the group that holds the block's first value; RLE: the byte behind the run
+    const uint32_t from = kind == kBitpacked ? rs.payload + (rs.skip >> 3) * w : rs.skip;
+    uint32_t pieces = ((((block_n * w) >> 3) + 64u) + (from & 15u) + 1023u) >> 10;
+    pieces = pieces > 4u ? 4u : pieces;
+    if (kind == kRle && (alone || from == kEndPos)) pieces = 0;  // the block takes no bytes from the stream
+    f.rs = rs;
+    f.from16 = from & ~15u;
+    f.pieces = pieces;
+#pragma unroll
+    for (uint32_t i = 0; i < 4; ++i)
+        if (i < pieces) f.piece[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, f.from16 + i * 1024u + lane * 16u, 0, 0);
+    f.hp = kEndPos;
+    if (!alone && lane < 63u) f.hp = hdrs[rs.run_index + 1u + lane];
+}
+
 // One wave decodes block [block_start, block_start + block_n) of a page whose
-// width is W.  `tbl` (kTableRuns + 2 entries) and `win` are the wave's LDS.
+// width is W.  `tbl` (kTableRuns + 2 entries) and `win` are the wave's LDS; the
+// window holds what fetch_block asked for and `hp_first` are its header
+// positions.
 template <int W>
 __device__ __forceinline__ void expand_block(const __amdgpu_buffer_rsrc_t rsrc, Window &win, uint2 *tbl,
-                                             const Resume rs, const uint32_t *__restrict__ hdrs,
-                                             const uint32_t end, const uint32_t n, const uint32_t block_start,
-                                             const uint32_t block_n, uint32_t *out, const uint32_t lane) {
+                                             const Resume rs, const uint32_t hp_first,
+                                             const uint32_t *__restrict__ hdrs, const uint32_t end, const uint32_t n,
+                                             const uint32_t block_start, const uint32_t block_n, out_u32 *out,
+                                             const uint32_t lane) {
     constexpr uint32_t w = (uint32_t)W;
     constexpr uint32_t kMaxVals = ((kWinBytes - 64u) / w) * 8u;  // values of one span that surely fit the window
     constexpr uint32_t kLaneRuns = kTableRuns - 1;               // runs decoded by lanes in one pass
@@ -374,8 +411,9 @@ __device__ __forceinline__ void expand_block(const __amdgpu_buffer_rsrc_t rsrc, 
     uint32_t kind = rs.rem_kind >> 31;
     uint32_t rem = rs.rem_kind & kRemMask;
     uint32_t payload = rs.payload;  // RLE: the value
-    uint32_t skip = rs.skip;
+    uint32_t skip = rs.skip;        // bit-packed only
     uint32_t ridx = rs.run_index;
+    bool first_pass = true;
 
     const uint32_t mis = (uint32_t)(((uintptr_t)out >> 2) & 3u);  // values between the 16-byte grid and `out`
     uint32_t lo = 0;                                               // block positions [0, lo) are written
@@ -402,7 +440,10 @@ __device__ __forceinline__ void expand_block(const __amdgpu_buffer_rsrc_t rsrc, 
         uint32_t hp = kEndPos;
         if (!alone) {
             // lane r <- run ridx + 1 + r: position, header, length; a prefix sum places them
-            if (lane < kLaneRuns) hp = hdrs[ridx + 1u + lane];
+            if (first_pass)
+                hp = hp_first;
+            else if (lane < kLaneRuns)
+                hp = hdrs[ridx + 1u + lane];
             const uint32_t hp0 = __builtin_amdgcn_readfirstlane(hp);
             if (hp0 != kEndPos && !win.holds(hp0 & ~3u, (hp0 & ~3u) + 24u)) {
                 if (kind == kRle) win.fill(rsrc, hp0, est, lane);  // nothing of this pass lives in the window yet
@@ -422,8 +463,8 @@ __device__ __forceinline__ void expand_block(const __amdgpu_buffer_rsrc_t rsrc, 
             }
             const uint64_t bad = __ballot(!ok);  // lane 63 is never valid
             g = (uint32_t)__builtin_ctzll(bad);
-            const uint32_t start_g = __shfl(start, (int)g, 64);
-            const uint32_t hp_g = __shfl(hp, (int)g, 64);
+            const uint32_t start_g = __builtin_amdgcn_readlane(start, g);  // wave-uniform, and known to be
+            const uint32_t hp_g = __builtin_amdgcn_readlane(hp, g);
             const bool ends = g < kLaneRuns && hp_g == kEndPos;  // no more runs: zeros follow (mod.rs:95)
             if (lane < g && start < block_n) {
                 key = (start << 1) | run.kind;
@@ -474,6 +515,7 @@ __device__ __forceinline__ void expand_block(const __amdgpu_buffer_rsrc_t rsrc, 
         }
 
         // ---- next pass (rare: more than 63 runs in the block, or bytes beyond the window) -----------------
+        first_pass = false;
         if (hi < block_n) {
             if (alone) {  // the first run continues
                 rem -= take0;
@@ -496,33 +538,63 @@ __device__ __forceinline__ void expand_block(const __amdgpu_buffer_rsrc_t rsrc, 
     }
 }
 
+// One wave decodes the (up to) four blocks of one tile of a page whose width is
+// W, one after the other; while it works on a block, the bytes and header
+// positions of the next one are on their way from memory.  `rs4`: lane j holds
+// the Resume entry of the tile's block j.
+template <int W>
+__device__ __forceinline__ void expand_tile(const __amdgpu_buffer_rsrc_t rsrc, Window &win, uint2 *tbl, const u32x4 rs4,
+                                            const uint32_t *__restrict__ hdrs, const uint32_t end, const uint32_t n,
+                                            const uint32_t tile_first, out_u32 *out, const uint32_t lane) {
+    const uint32_t blocks = min(kBlocksPerTile, (n - tile_first + kBlockValues - 1u) / kBlockValues);
+    auto resume_of = [&](uint32_t j) {
+        Resume r;
+        r.run_index = __builtin_amdgcn_readlane(rs4.x, j);
+        r.rem_kind = __builtin_amdgcn_readlane(rs4.y, j);
+        r.payload = __builtin_amdgcn_readlane(rs4.z, j);
+        r.skip = __builtin_amdgcn_readlane(rs4.w, j);
+        return r;
+    };
+    auto length_of = [&](uint32_t j) { return min(kBlockValues, n - (tile_first + j * kBlockValues)); };
+    Fetch f;
+    fetch_block(f, rsrc, resume_of(0), hdrs, (uint32_t)W, length_of(0), lane);
+    for (uint32_t j = 0; j < blocks; ++j) {
+        win.put(f.piece, f.from16, f.pieces, lane);
+        const Resume rs = f.rs;
+        uint32_t hp = f.hp;
+        // the block's header positions are taken over here: no wait for them may come after the loads of the
+        // next block have been issued (memory operations complete in order, a later wait would cover those too)
+        asm volatile("" : "+v"(hp));
+        if (j + 1u < blocks) fetch_block(f, rsrc, resume_of(j + 1u), hdrs, (uint32_t)W, length_of(j + 1u), lane);
+        expand_block<W>(rsrc, win, tbl, rs, hp, hdrs, end, n, tile_first + j * kBlockValues, length_of(j),
+                        out + j * kBlockValues, lane);
+    }
+}
+
 #ifndef PQ2_EXPAND_WAVES
-#define PQ2_EXPAND_WAVES 6  // 75 VGPRs fit without spilling; 8 waves per SIMD would spill to scratch
+#define PQ2_EXPAND_WAVES 6
 #endif
+// One workgroup = four waves = four consecutive tiles of the round (tiles [tile_start, tile_end) in the batch-wide
+// numbering).
 __global__ __launch_bounds__(256, PQ2_EXPAND_WAVES) void expand_kernel(const PageDev *__restrict__ pages,
                                                        const uint32_t *__restrict__ tile_page,
                                                        const Resume *__restrict__ resume,
                                                        const uint32_t *__restrict__ run_pos,
-                                                       uint32_t tile_start, uint32_t round) {
-    __shared__ __attribute__((aligned(16))) uint8_t stage[kBlocksPerTile * kWinBytes];
-    __shared__ __attribute__((aligned(16))) uint2 table[kBlocksPerTile * (kTableRuns + 2)];
+                                                       uint32_t tile_start, uint32_t tile_end, uint32_t round) {
+    __shared__ __attribute__((aligned(16))) uint8_t stage[4 * kWinBytes];
+    __shared__ __attribute__((aligned(16))) uint2 table[4 * (kTableRuns + 2)];
 
-    const uint32_t tile = tile_start + blockIdx.x;  // batch-wide tile number; the tiles of one round are contiguous
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t tile = tile_start + blockIdx.x * 4u + wave;
+    if (tile >= tile_end) return;
 
+    u32x4 rs4 = {0u, 0u, 0u, 0u};
+    if (lane < kBlocksPerTile) rs4 = ((const u32x4 *)resume)[(size_t)tile * kBlocksPerTile + lane];
     const PageDev pg = pages[tile_page[tile]];
     const uint32_t n = pg.num_values;
-    const uint32_t block = (pg.round_first(round) + (tile - pg.round_base(round))) * kBlocksPerTile + wave;
-    const uint32_t block_start = block * kBlockValues;
-    if (block_start >= n) return;
-    const uint32_t block_n = min(kBlockValues, n - block_start);
-
-    Resume rs = resume[(size_t)tile * kBlocksPerTile + wave];
-    rs.run_index = __builtin_amdgcn_readfirstlane(rs.run_index);
-    rs.rem_kind = __builtin_amdgcn_readfirstlane(rs.rem_kind);
-    rs.payload = __builtin_amdgcn_readfirstlane(rs.payload);
-    rs.skip = __builtin_amdgcn_readfirstlane(rs.skip);
+    const uint32_t tile_first = (pg.round_first(round) + (tile - pg.round_base(round))) * kTileValues;
+    if (tile_first >= n) return;
 
     const uint32_t delta = (uint32_t)(pg.in_addr & 15u);
     const uint32_t end = delta + pg.in_len;
@@ -533,26 +605,31 @@ __global__ __launch_bounds__(256, PQ2_EXPAND_WAVES) void expand_kernel(const Pag
     win.lds = stage + wave * kWinBytes;
     uint2 *tbl = table + wave * (kTableRuns + 2);
     if (lane < 2) tbl[kTableRuns + lane] = make_uint2(kNoRun, 0u);  // read by tbl[j + 1] only
-    uint32_t *const out = (uint32_t *)pg.out_addr + block_start;
+    out_u32 *const out = (out_u32 *)pg.out_addr + tile_first;
 
     switch (pg.num_bits) {
-#define PQ2_W(N)                                                                             \
-    case N:                                                                                  \
-        expand_block<N>(rsrc, win, tbl, rs, run_pos + pg.run_base, end, n, block_start, block_n, out, lane); \
+#define PQ2_W(N)                                                                              \
+    case N:                                                                                   \
+        expand_tile<N>(rsrc, win, tbl, rs4, run_pos + pg.run_base, end, n, tile_first, out, lane); \
         break;
+#ifdef PQ2_ONLY_W  // single-width build for reading the generated code
+        PQ2_W(PQ2_ONLY_W)
+#else
         PQ2_W(1) PQ2_W(2) PQ2_W(3) PQ2_W(4) PQ2_W(5) PQ2_W(6) PQ2_W(7) PQ2_W(8)
         PQ2_W(9) PQ2_W(10) PQ2_W(11) PQ2_W(12) PQ2_W(13) PQ2_W(14) PQ2_W(15) PQ2_W(16)
         PQ2_W(17) PQ2_W(18) PQ2_W(19) PQ2_W(20) PQ2_W(21) PQ2_W(22) PQ2_W(23) PQ2_W(24)
         PQ2_W(25) PQ2_W(26) PQ2_W(27) PQ2_W(28) PQ2_W(29) PQ2_W(30) PQ2_W(31) PQ2_W(32)
+#endif
 #undef PQ2_W
-        default: {  // width 0 (or a skipped page): zeros
+        default: {  // width 0: zeros
+            const uint32_t count = min(kTileValues, n - tile_first);
             const u32x4 z = {0u, 0u, 0u, 0u};
-            const uint32_t head = min((4u - (uint32_t)(((uintptr_t)out >> 2) & 3u)) & 3u, block_n);
+            const uint32_t head = min((4u - (uint32_t)(((uintptr_t)out >> 2) & 3u)) & 3u, count);
             if (lane < head) out[lane] = 0u;
-            const uint32_t groups = (block_n - head) >> 2;
+            const uint32_t groups = (count - head) >> 2;
             for (uint32_t g = lane; g < groups; g += 64u) store4(z, out + head + 4u * g);
             const uint32_t tail = head + 4u * groups;
-            if (lane < block_n - tail) out[tail + lane] = 0u;
+            if (lane < count - tail) out[tail + lane] = 0u;
             break;
         }
     }
@@ -574,7 +651,7 @@ __global__ __launch_bounds__(256) void bitunpack_kernel(uint64_t in_addr, uint32
          block += gridDim.x * kBlocksPerTile) {
         const uint32_t start = block * kBlockValues;
         const uint32_t cnt = min(kBlockValues, length - start);
-        emit_bp_dispatch(w, rsrc, delta, start, out + start, cnt, lane);
+        emit_bp_dispatch(w, rsrc, delta, start, (out_u32 *)(out + start), cnt, lane);
     }
 }
 
@@ -595,8 +672,9 @@ extern "C" hipError_t pq2_launch_expand(const void *pages, const uint32_t *tile_
                                         uint32_t n_tiles, const void *resume, const uint32_t *run_pos, uint32_t round,
                                         hipStream_t stream) {
     if (n_tiles == 0) return hipSuccess;
-    hipLaunchKernelGGL(pq2::expand_kernel, dim3(n_tiles), dim3(256), 0, stream, (const pq2::PageDev *)pages,
-                       tile_page, (const pq2::Resume *)resume, run_pos, tile_start, round);
+    hipLaunchKernelGGL(pq2::expand_kernel, dim3((n_tiles + 3u) / 4u), dim3(256), 0, stream,
+                       (const pq2::PageDev *)pages, tile_page, (const pq2::Resume *)resume, run_pos, tile_start,
+                       tile_start + n_tiles, round);
     return hipGetLastError();
 }
 

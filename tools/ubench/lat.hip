@@ -130,7 +130,9 @@ __global__ void salu_indep(uint64_t *out, uint32_t x) {
             : "+s"(a), "+s"(b), "+s"(c), "+s"(d)::"scc");
     }
     uint64_t t1 = __builtin_readcyclecounter();
-    if (threadIdx.x == 0) out[0] = t1 - t0, out[1] = a + b + c + d;
+    // the slowest wave counts: the issue arbiter favours the oldest wave
+    if ((threadIdx.x & 63) == 0) atomicMax((unsigned long long *)&out[0], (unsigned long long)(t1 - t0));
+    if (threadIdx.x == 0) out[1] = a + b + c + d;
 }
 
 // 16 dependent vector adds per iteration
@@ -188,6 +190,42 @@ __global__ void branch_cost(uint64_t *out, uint32_t x, int unrolled) {
     if (threadIdx.x == 0) out[0] = t1 - t0, out[1] = s;
 }
 
+// integer VALU throughput of one SIMD: `waves_per_simd` waves per SIMD (blockDim = 256 * waves_per_simd), each
+// with 4 independent chains of the given instruction
+template <int KIND>
+__global__ void valu_tput(uint64_t *out, uint32_t x) {
+    uint32_t a = x + threadIdx.x, b = a * 3, c = a * 5, d = a * 7;
+    __syncthreads();
+    uint64_t t0 = __builtin_readcyclecounter();
+    for (int i = 0; i < REP; ++i) {
+        if (KIND == 0)
+            asm volatile(
+                "v_add_u32 %0, %0, 3\n\tv_add_u32 %1, %1, 3\n\tv_add_u32 %2, %2, 3\n\tv_add_u32 %3, %3, 3\n\t"
+                "v_add_u32 %0, %0, 3\n\tv_add_u32 %1, %1, 3\n\tv_add_u32 %2, %2, 3\n\tv_add_u32 %3, %3, 3\n\t"
+                "v_add_u32 %0, %0, 3\n\tv_add_u32 %1, %1, 3\n\tv_add_u32 %2, %2, 3\n\tv_add_u32 %3, %3, 3\n\t"
+                "v_add_u32 %0, %0, 3\n\tv_add_u32 %1, %1, 3\n\tv_add_u32 %2, %2, 3\n\tv_add_u32 %3, %3, 3"
+                : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        else if (KIND == 1)
+            asm volatile(
+                "v_alignbit_b32 %0, %1, %0, 3\n\tv_alignbit_b32 %1, %2, %1, 3\n\tv_alignbit_b32 %2, %3, %2, 3\n\tv_alignbit_b32 %3, %0, %3, 3\n\t"
+                "v_alignbit_b32 %0, %1, %0, 3\n\tv_alignbit_b32 %1, %2, %1, 3\n\tv_alignbit_b32 %2, %3, %2, 3\n\tv_alignbit_b32 %3, %0, %3, 3\n\t"
+                "v_alignbit_b32 %0, %1, %0, 3\n\tv_alignbit_b32 %1, %2, %1, 3\n\tv_alignbit_b32 %2, %3, %2, 3\n\tv_alignbit_b32 %3, %0, %3, 3\n\t"
+                "v_alignbit_b32 %0, %1, %0, 3\n\tv_alignbit_b32 %1, %2, %1, 3\n\tv_alignbit_b32 %2, %3, %2, 3\n\tv_alignbit_b32 %3, %0, %3, 3"
+                : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        else
+            asm volatile(
+                "v_fma_f32 %0, %0, %0, %0\n\tv_fma_f32 %1, %1, %1, %1\n\tv_fma_f32 %2, %2, %2, %2\n\tv_fma_f32 %3, %3, %3, %3\n\t"
+                "v_fma_f32 %0, %0, %0, %0\n\tv_fma_f32 %1, %1, %1, %1\n\tv_fma_f32 %2, %2, %2, %2\n\tv_fma_f32 %3, %3, %3, %3\n\t"
+                "v_fma_f32 %0, %0, %0, %0\n\tv_fma_f32 %1, %1, %1, %1\n\tv_fma_f32 %2, %2, %2, %2\n\tv_fma_f32 %3, %3, %3, %3\n\t"
+                "v_fma_f32 %0, %0, %0, %0\n\tv_fma_f32 %1, %1, %1, %1\n\tv_fma_f32 %2, %2, %2, %2\n\tv_fma_f32 %3, %3, %3, %3"
+                : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    }
+    uint64_t t1 = __builtin_readcyclecounter();
+    // the slowest wave counts: the issue arbiter favours the oldest wave
+    if ((threadIdx.x & 63) == 0) atomicMax((unsigned long long *)&out[0], (unsigned long long)(t1 - t0));
+    if (threadIdx.x == 0) out[1] = a + b + c + d;
+}
+
 __global__ void clocks(uint64_t *out) {
     uint64_t c0 = __builtin_readcyclecounter(), w0 = wall_clock64();
     uint32_t v = threadIdx.x;
@@ -200,6 +238,7 @@ __global__ void clocks(uint64_t *out) {
     do {                                                                             \
         hipLaunchKernelGGL(__VA_ARGS__);                                             \
         hipDeviceSynchronize();                                                      \
+        hipMemset(d, 0, 64);                                                         \
         hipLaunchKernelGGL(__VA_ARGS__);                                             \
         hipDeviceSynchronize();                                                      \
         hipMemcpy(h, d, 32, hipMemcpyDeviceToHost);                                  \
@@ -239,6 +278,15 @@ int main() {
     RUN("v_readlane dependent", 8, readlane_chain, dim3(1), dim3(64), 0, 0, d, 1u);
     RUN("7-instruction loop, taken branch each", 8, branch_cost, dim3(1), dim3(64), 0, 0, d, 1u, 0);
     RUN("7-instruction loop, taken branch every 2nd", 8, branch_cost, dim3(1), dim3(64), 0, 0, d, 1u, 1);
+    for (int wps = 1; wps <= 4; wps *= 2) {
+        char name[96];
+        snprintf(name, sizeof name, "v_add_u32, %d waves per SIMD (per wave)", wps);
+        RUN(name, 16, valu_tput<0>, dim3(1), dim3(256 * wps), 0, 0, d, 1u);
+        snprintf(name, sizeof name, "v_alignbit_b32, %d waves per SIMD (per wave)", wps);
+        RUN(name, 16, valu_tput<1>, dim3(1), dim3(256 * wps), 0, 0, d, 1u);
+        snprintf(name, sizeof name, "v_fma_f32, %d waves per SIMD (per wave)", wps);
+        RUN(name, 16, valu_tput<2>, dim3(1), dim3(256 * wps), 0, 0, d, 1u);
+    }
     // the same with every SIMD of the chip busy (1024 waves)
     RUN("ds_read_b64 +3 chain, 1024 waves", 1, lds_chain<8>, dim3(1024), dim3(64), 0, 0, d, 3u);
     RUN("s_add_u32 dependent, 1024 waves", 16, salu_chain, dim3(1024), dim3(64), 0, 0, d, 1u);

@@ -22,7 +22,8 @@ extern "C" {
 hipError_t pq2_launch_parse(const void *pages, uint32_t n_pages, void *resume, uint32_t *tile_page, uint32_t *run_pos,
                             int32_t *status, void *state, uint32_t round, hipStream_t stream);
 hipError_t pq2_launch_expand(const void *pages, const uint32_t *tile_page, uint32_t tile_start, uint32_t n_tiles,
-                             const void *resume, const uint32_t *run_pos, uint32_t round, hipStream_t stream);
+                             const void *resume, const uint32_t *run_pos, uint32_t round, uint32_t max_bits,
+                             hipStream_t stream);
 hipError_t pq2_launch_bitunpack(const void *d_packed, uint32_t packed_len, uint32_t num_bits, uint32_t length,
                                 uint32_t *d_out, hipStream_t stream);
 }
@@ -163,6 +164,7 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
     PageDev *pages = static_cast<PageDev *>(ctx->h_meta);
 
     uint64_t tiles = 0, run_entries = 0;
+    uint32_t max_bits = 0;  // over the pages that are decoded
     for (uint64_t i = 0; i < n_pages; ++i) {
         const pq2_page_desc &d = descs[i];
         if (d.in_len > PQ2_MAX_PAGE_BYTES) return fail(ctx, PQ2_INVALID_PARAMETER, "page stream too long");
@@ -183,6 +185,7 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
         }
         const uint64_t page_tiles = (uint64_t(p.num_values) + kTileValues - 1) / kTileValues;
         p.reserved = 0;
+        if (p.num_values > 0) max_bits = std::max(max_bits, p.num_bits);
         // header-position list: a run that yields values takes >= 2 stream bytes and >= 1 value; + the closing
         // entry, + the 64 entries a wave may read past the last one, rounded to whole 64-entry stores
         p.run_base = run_entries;
@@ -287,7 +290,7 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
         if ((st = stamped(true, es[r & 1u], [&] {
                  return pq2_launch_expand(d_pages, d_tile_page, static_cast<uint32_t>(round_start[r]),
                                           static_cast<uint32_t>(round_start[r + 1] - round_start[r]),
-                                          ctx->d_resume.ptr, d_run_pos, r, es[r & 1u]);
+                                          ctx->d_resume.ptr, d_run_pos, r, max_bits, es[r & 1u]);
              })))
             return st;
     }

@@ -322,13 +322,25 @@ __device__ __forceinline__ LaneRun decode_lane(const uint8_t *lds, uint32_t off,
     return r;
 }
 
-// Inclusive prefix sum over the 64 lanes of a wave.
-__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v, uint32_t lane) {
-#pragma unroll
-    for (uint32_t d = 1; d < 64; d <<= 1) {
-        const uint32_t t = __shfl_up(v, d, 64);
-        if (lane >= d) v += t;
-    }
+// Inclusive prefix operations over the 64 lanes of a wave with DPP row shifts and row broadcasts: six
+// instructions (row_shr 1, 2, 4, 8 inside the rows of 16 lanes, then the last lane of row 0 / 2 into row 1 / 3
+// and the last lane of row 1 into rows 2 and 3).  0 is the identity of both operations.
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_inclusive_max(uint32_t v) {
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0u, v, 0x111, 0xf, 0xf, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0u, v, 0x112, 0xf, 0xf, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0u, v, 0x114, 0xf, 0xf, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0u, v, 0x118, 0xf, 0xf, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0u, v, 0x142, 0xa, 0xf, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0u, v, 0x143, 0xc, 0xf, false));
     return v;
 }
 
@@ -345,41 +357,36 @@ __device__ __forceinline__ void store4(u32x4 v, out_u32 *p) {
 }
 
 // ---- LDS-staged stream window --------------------------------------------------
-// Each wave of expand_kernel owns kWinBytes of LDS holding stream bytes
-// [lo, hi) (a-coordinates, lo 16-byte aligned).  A refill is 1..4 coalesced
-// dwordx4 loads of the whole wave (1 KiB each) -- one memory round trip --
-// after which run headers and bit-packed fields are read from LDS.  The region
-// is private to the wave: LDS operations of one wave execute in order, so no
-// barrier is needed between the fill and the reads.
-constexpr uint32_t kWinBytes = 4096;
-
+// Each wave of expand_kernel owns `cap` bytes of LDS holding stream bytes
+// [lo, hi) (a-coordinates, lo 16-byte aligned).  A fill is a series of coalesced
+// dwordx4 loads of the whole wave (1 KiB each) that are all in flight together --
+// one memory round trip -- after which run headers and bit-packed fields are
+// read from LDS.  The region is private to the wave: LDS operations of one wave
+// execute in order, so no barrier is needed between the fill and the reads.
 struct Window {
-    uint32_t lo, hi;  // resident a-offsets [lo, hi)
-    uint8_t *lds;     // this wave's kWinBytes
+    uint32_t lo, hi;    // resident a-offsets [lo, hi)
+    uint8_t *lds;       // this wave's region
+    uint32_t cap;       // its size in bytes (a multiple of 16, at least 2048)
+    uint32_t bit_mask;  // 8 * (the power of two >= cap) - 1: keeps any bit position inside the workgroup's LDS
 
+    // makes [from & ~15, ...) resident: `need` bytes from `from`, as far as the region goes
     __device__ __forceinline__ void fill(__amdgpu_buffer_rsrc_t rsrc, uint32_t from, uint32_t need, uint32_t lane) {
         lo = from & ~15u;
-        uint32_t pieces = (need + (from & 15u) + 1023u) >> 10;
-        pieces = pieces < 1u ? 1u : (pieces > 4u ? 4u : pieces);
-        u32x4 v[4];
+        const uint32_t bytes = min((need + (from & 15u) + 1023u) & ~1023u, cap);
+        for (uint32_t base = 0; base < bytes; base += 4096u) {  // four pieces at a time
+            u32x4 v[4];
 #pragma unroll
-        for (uint32_t i = 0; i < 4; ++i)
-            if (i < pieces) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lo + i * 1024u + lane * 16u, 0, 0);
+            for (uint32_t i = 0; i < 4; ++i) {
+                const uint32_t at = base + i * 1024u + lane * 16u;
+                if (at < bytes) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lo + at, 0, 0);
+            }
 #pragma unroll
-        for (uint32_t i = 0; i < 4; ++i)
-            if (i < pieces) *(u32x4 *)(lds + i * 1024u + lane * 16u) = v[i];
-        hi = lo + pieces * 1024u;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
-    // the window takes over `pieces` KiB fetched earlier into registers (lane L of piece i: bytes
-    // [from16 + i * 1024 + L * 16, + 16))
-    __device__ __forceinline__ void put(const u32x4 *v, uint32_t from16, uint32_t pieces, uint32_t lane) {
-        lo = from16;
-#pragma unroll
-        for (uint32_t i = 0; i < 4; ++i)
-            if (i < pieces) *(u32x4 *)(lds + i * 1024u + lane * 16u) = v[i];
-        hi = lo + pieces * 1024u;
+            for (uint32_t i = 0; i < 4; ++i) {
+                const uint32_t at = base + i * 1024u + lane * 16u;
+                if (at < bytes) *(u32x4 *)(lds + at) = v[i];
+            }
+        }
+        hi = lo + bytes;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
@@ -394,6 +401,34 @@ __device__ __forceinline__ uint32_t field_at(const uint8_t *lds, uint32_t bit) {
     const uint32_t x = __builtin_amdgcn_alignbit(src[1], src[0], bit & 31u);
     constexpr uint32_t mask = W == 32 ? 0xffffffffu : ((1u << (W & 31)) - 1u);
     return x & mask;
+}
+
+// Four consecutive W-bit fields starting at LDS bit position `bit`: ceil(4W / 32) + 1 dword reads, one funnel
+// shift per dword to bring the first field to bit 0, then one extraction per field at a constant position.
+template <int W>
+__device__ __forceinline__ u32x4 fields4_at(const uint8_t *lds, uint32_t bit) {
+    constexpr int NY = (4 * W + 31) / 32;
+    const uint32_t *src = (const uint32_t *)(lds + ((bit >> 3) & ~3u));
+    const uint32_t s = bit & 31u;
+    uint32_t x[NY + 1];
+#pragma unroll
+    for (int i = 0; i <= NY; ++i) x[i] = src[i];
+    uint32_t y[NY];
+#pragma unroll
+    for (int i = 0; i < NY; ++i) y[i] = __builtin_amdgcn_alignbit(x[i + 1], x[i], s);
+    constexpr uint32_t mask = W == 32 ? 0xffffffffu : ((1u << (W & 31)) - 1u);
+    uint32_t o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int lo = (i * W) >> 5;
+        const int shf = (i * W) & 31;
+        if (shf + W <= 32)
+            o[i] = W == 32 ? y[lo] : ((y[lo] >> shf) & mask);
+        else
+            o[i] = __builtin_amdgcn_alignbit(y[lo + 1 < NY ? lo + 1 : lo], y[lo], shf) & mask;
+    }
+    const u32x4 res = {o[0], o[1], o[2], o[3]};
+    return res;
 }
 
 // ---- direct-from-memory extraction (bitunpack_kernel: no headers, no staging) -------------

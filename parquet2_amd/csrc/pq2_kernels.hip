@@ -360,52 +360,53 @@ __global__ __launch_bounds__(64) void parse_kernel(const PageDev *__restrict__ p
 // ---------------------------------------------------------------------------
 // expand_kernel
 // ---------------------------------------------------------------------------
-constexpr uint32_t kTableRuns = 64;      // run-table entries per wave (the last one stays a sentinel)
-constexpr uint32_t kNoRun = 0xffffffffu; // table key of an unused entry: compares greater than any position
+constexpr uint32_t kTableRuns = 64;       // run-table entries per wave (the last one stays a sentinel)
+constexpr uint32_t kNoRun = 0xffffffffu;  // table key of an unused entry: compares greater than any position
+#ifndef PQ2_SPAN_BLOCKS
+#define PQ2_SPAN_BLOCKS 2
+#endif
+// expand_kernel works through a tile in spans of kSpanBlocks blocks: one run table, one chunk index and one set
+// of emission steps per span (the Resume entry of a span's first block says where it starts; those of the
+// other blocks are not needed).
+constexpr uint32_t kSpanBlocks = PQ2_SPAN_BLOCKS;  // 1, 2 or 4
+constexpr uint32_t kSpanValues = kSpanBlocks * kBlockValues;
+constexpr uint32_t kSpanChunks = kSpanValues / 4u;     // chunks of 4 values per span ...
+constexpr uint32_t kChunkSlots = kSpanChunks + 8u;     // ... + 2 when the output is not 16-byte aligned, rounded up
 
-// The stream bytes and header positions a block starts from, requested from memory one block ahead of the
-// block's turn.
-struct Fetch {
-    u32x4 piece[4];   // lane L of piece i: stream bytes [from16 + i * 1024 + L * 16, + 16)
-    uint32_t hp;      // lane r < 63: position of header rs.run_index + 1 + r; kEndPos elsewhere
-    uint32_t from16;  // a-offset of the first byte (16-byte aligned)
-    uint32_t pieces;  // 0..4
-    Resume rs;        // where the block starts (wave-uniform)
-};
-
-__device__ __forceinline__ void fetch_block(Fetch &f, const __amdgpu_buffer_rsrc_t rsrc, const Resume rs,
-                                            const uint32_t *__restrict__ hdrs, const uint32_t w,
-                                            const uint32_t block_n, const uint32_t lane) {
-    const uint32_t kind = rs.rem_kind >> 31;
-    const bool alone = (rs.rem_kind & kRemMask) >= block_n;  // the first run covers the whole block
-    // bit-packed: the group that holds the block's first value; RLE: the byte behind the run
-    const uint32_t from = kind == kBitpacked ? rs.payload + (rs.skip >> 3) * w : rs.skip;
-    uint32_t pieces = ((((block_n * w) >> 3) + 64u) + (from & 15u) + 1023u) >> 10;
-    pieces = pieces > 4u ? 4u : pieces;
-    if (kind == kRle && (alone || from == kEndPos)) pieces = 0;  // the block takes no bytes from the stream
-    f.rs = rs;
-    f.from16 = from & ~15u;
-    f.pieces = pieces;
-#pragma unroll
-    for (uint32_t i = 0; i < 4; ++i)
-        if (i < pieces) f.piece[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, f.from16 + i * 1024u + lane * 16u, 0, 0);
-    f.hp = kEndPos;
-    if (!alone && lane < 63u) f.hp = hdrs[rs.run_index + 1u + lane];
-}
-
-// One wave decodes block [block_start, block_start + block_n) of a page whose
-// width is W.  `tbl` (kTableRuns + 2 entries) and `win` are the wave's LDS; the
-// window holds what fetch_block asked for and `hp_first` are its header
-// positions.
+// One wave decodes the span [block_start, block_start + block_n) of a page
+// whose width is W (block_n <= kSpanValues).  `tbl` (kTableRuns + 2 entries), `cidx` (kChunkSlots entries) and
+// `win` are the wave's LDS; the window normally holds the block's stream bytes
+// already and `hp_first` are the positions of the headers behind its first run.
+//
+// A pass covers block positions [lo, hi) with at most 64 runs:
+//   phase 1  the first run comes from the Resume entry (or the previous pass);
+//            lane r decodes the header of run r + 1, a wave prefix sum of the
+//            run lengths gives every run its first position, and the runs go
+//            into the table: key = first position << 1 | kind, y = the RLE
+//            value, or for a bit-packed run the LDS bit position of its value
+//            at block position 0 (so that position p sits at y + p * W).
+//   index    output is produced in chunks of 4 values whose address is 16-byte
+//            aligned; chunk q holds positions [4q - mis, 4q - mis + 4).  Every
+//            run marks the first chunk that begins at or behind its first
+//            position, and a prefix maximum over the chunks turns the marks
+//            into "the run that holds the chunk's first position".
+//   phase 2  every lane takes one chunk per step.  A chunk that lies inside
+//            one run (nearly all do) takes its four fields out of the LDS
+//            image with one funnel shift per dword, or is four copies of the
+//            RLE value, and is written with one dwordx4.  The chunks that hold
+//            the first position of a run are left to one last step in which
+//            lane r works through the chunk that run r + 1 starts in, value
+//            by value.
 template <int W>
 __device__ __forceinline__ void expand_block(const __amdgpu_buffer_rsrc_t rsrc, Window &win, uint2 *tbl,
-                                             const Resume rs, const uint32_t hp_first,
+                                             uint32_t *cidx, const Resume rs, const uint32_t hp_first,
                                              const uint32_t *__restrict__ hdrs, const uint32_t end, const uint32_t n,
                                              const uint32_t block_start, const uint32_t block_n, out_u32 *out,
                                              const uint32_t lane) {
     constexpr uint32_t w = (uint32_t)W;
-    constexpr uint32_t kMaxVals = ((kWinBytes - 64u) / w) * 8u;  // values of one span that surely fit the window
     constexpr uint32_t kLaneRuns = kTableRuns - 1;               // runs decoded by lanes in one pass
+    const uint32_t max_vals = ((win.cap - 64u) / w) * 8u;        // values of one span that surely fit the window
+    const uint32_t bit_mask = win.bit_mask;
 
     // the first run of the pass (wave-uniform)
     uint32_t kind = rs.rem_kind >> 31;
@@ -418,112 +419,188 @@ __device__ __forceinline__ void expand_block(const __amdgpu_buffer_rsrc_t rsrc, 
     const uint32_t mis = (uint32_t)(((uintptr_t)out >> 2) & 3u);  // values between the 16-byte grid and `out`
     uint32_t lo = 0;                                               // block positions [0, lo) are written
 
-    while (lo < block_n) {
+    do {  // block_n > 0
         // ---- phase 1: the runs that cover [lo, hi) into the table ------------------------------------
         const uint32_t est = (((block_n - lo) * w) >> 3) + 64u;  // bytes the rest of the block is expected to need
         uint32_t take0 = min(rem, block_n - lo);
-        uint32_t info0 = payload;
+        uint32_t y0 = payload;
         bool alone = take0 == block_n - lo;  // the first run covers the rest of the block
         if (kind == kBitpacked) {
             const uint32_t b_lo = payload + (skip >> 3) * w;  // first byte of the group holding value `skip`
             uint32_t b_hi = payload + ((skip + take0 + 7u) >> 3) * w + 8u;
             if (!win.holds(b_lo & ~3u, b_hi)) {
-                if (take0 > kMaxVals) take0 = kMaxVals, alone = true;  // more than a window: this span only
+                if (take0 > max_vals) take0 = max_vals, alone = true;  // more than a window: this span only
                 b_hi = payload + ((skip + take0 + 7u) >> 3) * w + 8u;
                 win.fill(rsrc, b_lo, max(b_hi - b_lo + 16u, est), lane);
             }
-            info0 = (b_lo - win.lo) * 8u + (skip & 7u) * w;  // LDS bit position of the run's value `skip`
+            // LDS bit position of the run's value `skip`, which is block position lo
+            y0 = (b_lo - win.lo) * 8u + (skip & 7u) * w - lo * w;
         }
         uint32_t hi = lo + take0;
-        uint32_t key = kNoRun, info = 0;  // lane r: table entry r + 1
-        uint32_t g = 0;                   // lanes [0, g) hold usable runs
-        uint32_t hp = kEndPos;
-        if (!alone) {
-            // lane r <- run ridx + 1 + r: position, header, length; a prefix sum places them
-            if (first_pass)
-                hp = hp_first;
-            else if (lane < kLaneRuns)
-                hp = hdrs[ridx + 1u + lane];
-            const uint32_t hp0 = __builtin_amdgcn_readfirstlane(hp);
-            if (hp0 != kEndPos && !win.holds(hp0 & ~3u, (hp0 & ~3u) + 24u)) {
-                if (kind == kRle) win.fill(rsrc, hp0, est, lane);  // nothing of this pass lives in the window yet
-            }
-            const bool valid = hp != kEndPos && hp >= win.lo && (hp & ~3u) + 24u <= win.hi;
-            LaneRun run;
-            run.kind = kRle, run.count = 0, run.info = 0;
-            if (valid) run = decode_lane<W>(win.lds, hp - win.lo, hp, end);
-            const uint32_t cnt = min(run.count, 2048u);
-            const uint32_t start = hi + wave_inclusive_sum(cnt, lane) - cnt;
-            bool ok = valid;
-            uint32_t value = run.info;
-            if (run.kind == kBitpacked) {
-                const uint32_t t = start < block_n ? min(run.count, block_n - start) : 0u;
-                ok = ok && run.info + ((t + 7u) >> 3) * w + 8u <= win.hi;
-                value = (run.info - win.lo) * 8u;
-            }
-            const uint64_t bad = __ballot(!ok);  // lane 63 is never valid
-            g = (uint32_t)__builtin_ctzll(bad);
-            const uint32_t start_g = __builtin_amdgcn_readlane(start, g);  // wave-uniform, and known to be
-            const uint32_t hp_g = __builtin_amdgcn_readlane(hp, g);
-            const bool ends = g < kLaneRuns && hp_g == kEndPos;  // no more runs: zeros follow (mod.rs:95)
-            if (lane < g && start < block_n) {
-                key = (start << 1) | run.kind;
-                info = value;
-            }
-            if (ends && lane == g && start < block_n) key = (start << 1) | kRle;  // info stays 0
-            hi = (start_g >= block_n || ends) ? block_n : start_g;
-        }
-        tbl[(lane + 1u) & 63u] = lane == 63u ? make_uint2((lo << 1) | kind, info0) : make_uint2(key, info);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
 
-        // ---- phase 2: every lane produces 4 consecutive values per step ---------------------------------
-        // chunk q holds block positions [4q - mis, 4q - mis + 4): its address is 16-byte aligned
-        const uint32_t q_end = (hi + mis + 3u) >> 2;
-        for (uint32_t q = ((lo + mis) >> 2) + lane; q < q_end; q += 64u) {
-            const int32_t p = (int32_t)(q * 4u) - (int32_t)mis;
-            const uint32_t p0 = (uint32_t)max(p, (int32_t)lo);
-            // last table entry whose start is <= p0 (entry 0 starts at lo; unused entries compare greater)
-            const uint32_t probe = (p0 << 1) | 1u;
-            uint32_t j = 0;
+        if (alone && kind == kRle) {  // one value over the whole span: no table, no index
+            const u32x4 v = {payload, payload, payload, payload};
+            const uint32_t q_end = (hi + mis + 3u) >> 2;
+            for (uint32_t q = ((lo + mis) >> 2) + lane; q < q_end; q += 64u) {
+                const int32_t p = (int32_t)(q * 4u) - (int32_t)mis;
+                if (p >= (int32_t)lo && p + 4 <= (int32_t)hi) {
+                    store4(v, out + p);
+                } else {
 #pragma unroll
-            for (uint32_t step = kTableRuns / 2; step > 0; step >>= 1)
-                if (tbl[j + step].x <= probe) j += step;
-            uint2 cur = tbl[j];
-            uint32_t nxt = tbl[j + 1].x;
-            uint32_t v[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t pk = (uint32_t)max(p + k, (int32_t)p0);
-                if (((pk << 1) | 1u) >= nxt) {  // runs hold at least one value: one step forward is enough
-                    ++j;
-                    cur = tbl[j];
-                    nxt = tbl[j + 1].x;
+                    for (int k = 0; k < 4; ++k)
+                        if (p + k >= (int32_t)lo && p + k < (int32_t)hi) out[p + k] = payload;
                 }
-                const uint32_t bit = cur.y + (pk - (cur.x >> 1)) * w;
-                const uint32_t f = field_at<W>(win.lds, bit & (kWinBytes * 8u - 1u));
-                v[k] = (cur.x & 1u) ? cur.y : f;
             }
-            if (p >= (int32_t)lo && p + 4 <= (int32_t)hi) {
-                const u32x4 vv = {v[0], v[1], v[2], v[3]};
-                store4(vv, out + p);
-            } else {
+        } else {
+#pragma unroll
+            for (uint32_t i = 0; i < kSpanBlocks; ++i) *(u32x4 *)&cidx[4u * (lane + 64u * i)] = u32x4{0u, 0u, 0u, 0u};
+            if (lane < kChunkSlots - kSpanChunks) cidx[kSpanChunks + lane] = 0u;
+            uint32_t key = kNoRun, y = 0;  // lane r: table entry r + 1
+            uint32_t start = 0;            // block position of its first value
+            uint32_t g = 0;                // lanes [0, g) hold usable runs
+            if (!alone) {
+                // lane r <- run ridx + 1 + r: position, header, length; a prefix sum places them
+                uint32_t hp = kEndPos;
+                if (first_pass)
+                    hp = hp_first;
+                else if (lane < kLaneRuns)
+                    hp = hdrs[ridx + 1u + lane];
+                const uint32_t hp0 = __builtin_amdgcn_readfirstlane(hp);
+                if (hp0 != kEndPos && !win.holds(hp0 & ~3u, (hp0 & ~3u) + 24u)) {
+                    if (kind == kRle) win.fill(rsrc, hp0, est, lane);  // nothing of this pass lives in the window yet
+                }
+                const bool valid = hp != kEndPos && hp >= win.lo && (hp & ~3u) + 24u <= win.hi;
+                LaneRun run;
+                run.kind = kRle, run.count = 0, run.info = 0;
+                if (valid) run = decode_lane<W>(win.lds, hp - win.lo, hp, end);
+                const uint32_t cnt = min(run.count, 2u * kSpanValues);
+                start = hi + wave_inclusive_sum(cnt) - cnt;
+                bool ok = valid;
+                uint32_t value = run.info;
+                if (run.kind == kBitpacked) {
+                    const uint32_t t = start < block_n ? min(run.count, block_n - start) : 0u;
+                    ok = ok && run.info + ((t + 7u) >> 3) * w + 8u <= win.hi;
+                    value = (run.info - win.lo) * 8u - start * w;
+                }
+                const uint64_t bad = __ballot(!ok);  // lane 63 is never valid
+                g = (uint32_t)__builtin_ctzll(bad);
+                const uint32_t start_g = __builtin_amdgcn_readlane(start, g);
+                const uint32_t hp_g = __builtin_amdgcn_readlane(hp, g);
+                const bool ends = g < kLaneRuns && hp_g == kEndPos;  // no more runs: zeros follow (mod.rs:95)
+                if (lane < g && start < block_n) {
+                    key = (start << 1) | run.kind;
+                    y = value;
+                }
+                if (ends && lane == g && start < block_n) key = (start << 1) | kRle;  // y stays 0
+                hi = (start_g >= block_n || ends) ? block_n : start_g;
+            }
+            tbl[(lane + 1u) & 63u] = lane == 63u ? make_uint2((lo << 1) | kind, y0) : make_uint2(key, y);
+            // ---- index: the run that holds the first position of every chunk ---------------------------
+            if (key != kNoRun) atomicMax(&cidx[(start + mis + 3u) >> 2], lane + 1u);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (!alone) {
+                // lane l owns the 4 * kSpanBlocks consecutive chunks from 4 * kSpanBlocks * l on
+                u32x4 m[kSpanBlocks];
+                uint32_t run_max = 0;
+#pragma unroll
+                for (uint32_t i = 0; i < kSpanBlocks; ++i) {
+                    m[i] = *(const u32x4 *)&cidx[4u * (kSpanBlocks * lane + i)];
+                    m[i].x = max(m[i].x, run_max);
+                    m[i].y = max(m[i].x, m[i].y);
+                    m[i].z = max(m[i].y, m[i].z);
+                    m[i].w = max(m[i].z, m[i].w);
+                    run_max = m[i].w;
+                }
+                const uint32_t upto = wave_inclusive_max(run_max);
+                const uint32_t before = __builtin_amdgcn_update_dpp(0u, upto, 0x138, 0xf, 0xf, false);  // wave_shr:1
+#pragma unroll
+                for (uint32_t i = 0; i < kSpanBlocks; ++i) {
+                    m[i].x = max(m[i].x, before), m[i].y = max(m[i].y, before);
+                    m[i].z = max(m[i].z, before), m[i].w = max(m[i].w, before);
+                    *(u32x4 *)&cidx[4u * (kSpanBlocks * lane + i)] = m[i];
+                }
+                if (lane == 63u) {  // two more chunks exist when the output is not 16-byte aligned
+                    const uint32_t c0 = max(upto, cidx[kSpanChunks]);
+                    cidx[kSpanChunks] = c0;
+                    cidx[kSpanChunks + 1u] = max(c0, cidx[kSpanChunks + 1u]);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+
+            // ---- phase 2: one chunk per lane and step ---------------------------------------------------
+            // The steps do not depend on each other and there are at most 4 * kSpanBlocks + 1 of them (one more
+            // than the chunks of a span when the output is not 16-byte aligned): they are written out, without
+            // branches up to the store, so that the LDS reads of several steps (chunk index -> table entry ->
+            // stream dwords) are in flight together.
+            const uint32_t q_end = (hi + mis + 3u) >> 2;
+            const uint32_t q_first = ((lo + mis) >> 2) + lane;
+            bool ragged = false;  // some lane holds the first or last chunk of the span, and not all of it
+#pragma unroll
+            for (uint32_t step = 0; step < 4u * kSpanBlocks + 1u; ++step) {
+                const uint32_t q = q_first + 64u * step;
+                const bool active = q < q_end;
+                const int32_t p = (int32_t)(q * 4u) - (int32_t)mis;
+                const uint32_t j = cidx[min(q, kChunkSlots - 1u)];
+                // this entry and the key of the next one (two naturally aligned reads: a 16-byte read at an
+                // 8-byte boundary would be replayed)
+                const uint2 e = tbl[j];
+                const uint32_t nxt = tbl[j + 1u].x;
+                // no run starts behind the chunk's first position
+                const bool single = active && ((((uint32_t)(p + 3)) << 1) | 1u) < nxt;
+                const bool full = p >= (int32_t)lo && p + 4 <= (int32_t)hi;
+                const u32x4 f = fields4_at<W>(win.lds, (e.y + (uint32_t)p * w) & bit_mask);
+                const bool rle = (e.x & 1u) != 0u;
+                const u32x4 v = {rle ? e.y : f.x, rle ? e.y : f.y, rle ? e.y : f.z, rle ? e.y : f.w};
+                if (single && full) store4(v, out + p);
+                ragged = ragged || (single && !full);
+            }
+            if (__builtin_expect(__ballot(ragged) != 0, 0)) {
+                // the first and the last chunk of the span, where they lie inside one run: position by position
+#pragma unroll
+                for (uint32_t side = 0; side < 2u; ++side) {
+                    const uint32_t q = side == 0 ? (lo + mis) >> 2 : q_end - 1u;
+                    const int32_t p = (int32_t)(q * 4u) - (int32_t)mis;
+                    const int32_t pos = p + (int32_t)(lane & 3u);
+                    const uint32_t j = cidx[q];
+                    const uint2 e = tbl[j];
+                    const uint32_t nxt = tbl[j + 1u].x;
+                    const bool single = ((((uint32_t)(p + 3)) << 1) | 1u) < nxt;
+                    const bool full = p >= (int32_t)lo && p + 4 <= (int32_t)hi;
+                    const uint32_t f = field_at<W>(win.lds, (e.y + (uint32_t)pos * w) & bit_mask);
+                    if (lane < 4u && single && !full && pos >= (int32_t)lo && pos < (int32_t)hi)
+                        out[pos] = (e.x & 1u) ? e.y : f;
+                }
+            }
+            // the chunks in which a run starts: lane r takes the one of run r + 1, value by value
+            if (key != kNoRun) {
+                const uint32_t q = (start + mis) >> 2;
+                const int32_t p = (int32_t)(q * 4u) - (int32_t)mis;
+                uint32_t j = cidx[q];
+                uint2 cur = tbl[j];
+                uint32_t nxt = tbl[j + 1u].x;
+                uint32_t v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t pk = (uint32_t)max(p + k, (int32_t)lo);
+                    if (((pk << 1) | 1u) >= nxt) {  // runs hold at least one value: one step forward is enough
+                        ++j;
+                        cur = tbl[j];
+                        nxt = tbl[j + 1u].x;
+                    }
+                    const uint32_t f = field_at<W>(win.lds, (cur.y + pk * w) & bit_mask);
+                    v[k] = (cur.x & 1u) ? cur.y : f;
+                }
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     if (p + k >= (int32_t)lo && p + k < (int32_t)hi) out[p + k] = v[k];
             }
-        }
-
-        // ---- next pass (rare: more than 63 runs in the block, or bytes beyond the window) -----------------
-        first_pass = false;
-        if (hi < block_n) {
-            if (alone) {  // the first run continues
-                rem -= take0;
-                skip += take0;
-            } else {  // run ridx + 1 + g becomes the first run
+            // ---- next pass (rare: more than 63 runs in the block, or bytes beyond the window) --------------
+            if (hi < block_n && !alone) {  // run ridx + 1 + g becomes the first run
                 ridx += 1u + g;
                 const uint32_t at = __builtin_amdgcn_readfirstlane(hdrs[ridx]);
-                win.fill(rsrc, at, (((block_n - hi) * w) >> 3) + 64u, lane);
+                if (!win.holds(at & ~3u, (at & ~3u) + 24u)) win.fill(rsrc, at, (((block_n - hi) * w) >> 3) + 64u, lane);
                 auto rd = [&](uint32_t a) -> uint32_t { return __builtin_amdgcn_readfirstlane(win.dword(a)); };
                 const RunInfo run = decode_run(rd, at, end, w, n - (block_start + hi));
                 if (run.kind >= kEnd || run.count == 0) {  // cannot happen for a listed run; ends the block safely
@@ -534,55 +611,93 @@ __device__ __forceinline__ void expand_block(const __amdgpu_buffer_rsrc_t rsrc, 
                 }
             }
         }
+        if (hi < block_n && alone) {  // the first run continues
+            rem -= take0;
+            skip += take0;
+        }
+        first_pass = false;
         lo = hi;
-    }
+    } while (lo < block_n);
 }
 
 // One wave decodes the (up to) four blocks of one tile of a page whose width is
-// W, one after the other; while it works on a block, the bytes and header
-// positions of the next one are on their way from memory.  `rs4`: lane j holds
-// the Resume entry of the tile's block j.
+// W.  Everything the tile needs from memory is requested at once, before the
+// first value is stored: the stream bytes from the first byte any of its
+// blocks needs, as far as the tile is expected to reach (into the wave's LDS
+// window), and for every block the positions of the headers behind its first
+// run.  Memory operations complete in order, so a load issued behind a store
+// cannot be waited for without waiting for the store as well; this way no
+// block waits for the stores of the one before it.  `rs4`: lane j holds the
+// Resume entry of the tile's block j.
 template <int W>
-__device__ __forceinline__ void expand_tile(const __amdgpu_buffer_rsrc_t rsrc, Window &win, uint2 *tbl, const u32x4 rs4,
-                                            const uint32_t *__restrict__ hdrs, const uint32_t end, const uint32_t n,
-                                            const uint32_t tile_first, out_u32 *out, const uint32_t lane) {
-    const uint32_t blocks = min(kBlocksPerTile, (n - tile_first + kBlockValues - 1u) / kBlockValues);
-    auto resume_of = [&](uint32_t j) {
+__device__ __forceinline__ void expand_tile(const __amdgpu_buffer_rsrc_t rsrc, Window &win, uint2 *tbl,
+                                            uint32_t *cidx, const u32x4 rs4, const uint32_t *__restrict__ hdrs,
+                                            const uint32_t end, const uint32_t n, const uint32_t tile_first,
+                                            out_u32 *out, const uint32_t lane) {
+    constexpr uint32_t w = (uint32_t)W;
+    constexpr uint32_t kSpans = kBlocksPerTile / kSpanBlocks;  // spans per tile
+    const uint32_t spans = min(kSpans, (n - tile_first + kSpanValues - 1u) / kSpanValues);
+    // lane j holds the Resume entry of block j; span i starts with block i * kSpanBlocks
+    auto resume_of = [&](uint32_t i) {
         Resume r;
-        r.run_index = __builtin_amdgcn_readlane(rs4.x, j);
-        r.rem_kind = __builtin_amdgcn_readlane(rs4.y, j);
-        r.payload = __builtin_amdgcn_readlane(rs4.z, j);
-        r.skip = __builtin_amdgcn_readlane(rs4.w, j);
+        r.run_index = __builtin_amdgcn_readlane(rs4.x, i * kSpanBlocks);
+        r.rem_kind = __builtin_amdgcn_readlane(rs4.y, i * kSpanBlocks);
+        r.payload = __builtin_amdgcn_readlane(rs4.z, i * kSpanBlocks);
+        r.skip = __builtin_amdgcn_readlane(rs4.w, i * kSpanBlocks);
         return r;
     };
-    auto length_of = [&](uint32_t j) { return min(kBlockValues, n - (tile_first + j * kBlockValues)); };
-    Fetch f;
-    fetch_block(f, rsrc, resume_of(0), hdrs, (uint32_t)W, length_of(0), lane);
-    for (uint32_t j = 0; j < blocks; ++j) {
-        win.put(f.piece, f.from16, f.pieces, lane);
-        const Resume rs = f.rs;
-        uint32_t hp = f.hp;
-        // the block's header positions are taken over here: no wait for them may come after the loads of the
-        // next block have been issued (memory operations complete in order, a later wait would cover those too)
-        asm volatile("" : "+v"(hp));
-        if (j + 1u < blocks) fetch_block(f, rsrc, resume_of(j + 1u), hdrs, (uint32_t)W, length_of(j + 1u), lane);
-        expand_block<W>(rsrc, win, tbl, rs, hp, hdrs, end, n, tile_first + j * kBlockValues, length_of(j),
-                        out + j * kBlockValues, lane);
+    auto length_of = [&](uint32_t i) { return min(kSpanValues, n - (tile_first + i * kSpanValues)); };
+
+    // lane j = i * kSpanBlocks: does span i take bytes from the stream, and from where on
+    uint32_t from = kEndPos;
+    bool alone = true;
+    if (lane < kBlocksPerTile && lane % kSpanBlocks == 0u && lane / kSpanBlocks < spans) {
+        const uint32_t kind = rs4.y >> 31;
+        alone = (rs4.y & kRemMask) >= length_of(lane / kSpanBlocks);  // the first run covers the whole span
+        // bit-packed: the group that holds the span's first value; RLE: the byte behind the run
+        const uint32_t at = kind == kBitpacked ? rs4.z + (rs4.w >> 3) * w : rs4.w;
+        if (!(kind == kRle && alone)) from = at;  // kEndPos where the stream is exhausted
+    }
+    // header positions: lane r < 63 of hp[i] <- position of header run_index(i) + 1 + r
+    uint32_t hp[kSpans];
+#pragma unroll
+    for (uint32_t i = 0; i < kSpans; ++i) {
+        hp[i] = kEndPos;
+        const bool wanted = i < spans && !__builtin_amdgcn_readlane((uint32_t)alone, i * kSpanBlocks);
+        if (wanted && lane < 63u) hp[i] = hdrs[__builtin_amdgcn_readlane(rs4.x, i * kSpanBlocks) + 1u + lane];
+    }
+    // the spans lie one behind the other in the stream: the first one that needs bytes needs the earliest
+    uint32_t tile_from = kEndPos, first_needing = 0;
+#pragma unroll
+    for (uint32_t i = kSpans; i-- > 0;) {
+        const uint32_t fi = __builtin_amdgcn_readlane(from, i * kSpanBlocks);
+        if (fi != kEndPos) tile_from = fi, first_needing = i;
+    }
+    if (tile_from != kEndPos) {
+        const uint32_t values = min(kTileValues - first_needing * kSpanValues, n - (tile_first + first_needing * kSpanValues));
+        win.fill(rsrc, tile_from, ((values * w) >> 3) + (values >> 3) + 128u, lane);
+    }
+    for (uint32_t i = 0; i < spans; ++i) {
+        uint32_t hpi = hp[0];
+#pragma unroll
+        for (uint32_t k = 1; k < kSpans; ++k) hpi = i == k ? hp[k] : hpi;
+        expand_block<W>(rsrc, win, tbl, cidx, resume_of(i), hpi, hdrs, end, n, tile_first + i * kSpanValues,
+                        length_of(i), out + i * kSpanValues, lane);
     }
 }
 
 #ifndef PQ2_EXPAND_WAVES
-#define PQ2_EXPAND_WAVES 6
+#define PQ2_EXPAND_WAVES 5
 #endif
 // One workgroup = four waves = four consecutive tiles of the round (tiles [tile_start, tile_end) in the batch-wide
-// numbering).
+// numbering).  Dynamic LDS: four windows of `win_bytes` each, 32 spare bytes, four run tables, four chunk indexes.
 __global__ __launch_bounds__(256, PQ2_EXPAND_WAVES) void expand_kernel(const PageDev *__restrict__ pages,
                                                        const uint32_t *__restrict__ tile_page,
                                                        const Resume *__restrict__ resume,
                                                        const uint32_t *__restrict__ run_pos,
-                                                       uint32_t tile_start, uint32_t tile_end, uint32_t round) {
-    __shared__ __attribute__((aligned(16))) uint8_t stage[4 * kWinBytes];
-    __shared__ __attribute__((aligned(16))) uint2 table[4 * (kTableRuns + 2)];
+                                                       uint32_t tile_start, uint32_t tile_end, uint32_t round,
+                                                       uint32_t win_bytes, uint32_t win_bit_mask) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
@@ -602,15 +717,18 @@ __global__ __launch_bounds__(256, PQ2_EXPAND_WAVES) void expand_kernel(const Pag
 
     Window win;
     win.lo = win.hi = 0;
-    win.lds = stage + wave * kWinBytes;
-    uint2 *tbl = table + wave * (kTableRuns + 2);
+    win.lds = lds + wave * win_bytes;
+    win.cap = win_bytes;
+    win.bit_mask = win_bit_mask;
+    uint2 *tbl = (uint2 *)(lds + 4u * win_bytes + 32u) + wave * (kTableRuns + 2);
+    uint32_t *cidx = (uint32_t *)(lds + 4u * win_bytes + 32u + 4u * (kTableRuns + 2) * 8u) + wave * kChunkSlots;
     if (lane < 2) tbl[kTableRuns + lane] = make_uint2(kNoRun, 0u);  // read by tbl[j + 1] only
     out_u32 *const out = (out_u32 *)pg.out_addr + tile_first;
 
     switch (pg.num_bits) {
-#define PQ2_W(N)                                                                              \
-    case N:                                                                                   \
-        expand_tile<N>(rsrc, win, tbl, rs4, run_pos + pg.run_base, end, n, tile_first, out, lane); \
+#define PQ2_W(N)                                                                                    \
+    case N:                                                                                         \
+        expand_tile<N>(rsrc, win, tbl, cidx, rs4, run_pos + pg.run_base, end, n, tile_first, out, lane); \
         break;
 #ifdef PQ2_ONLY_W  // single-width build for reading the generated code
         PQ2_W(PQ2_ONLY_W)
@@ -667,14 +785,24 @@ extern "C" hipError_t pq2_launch_parse(const void *pages, uint32_t n_pages, void
     return hipGetLastError();
 }
 
-// the tiles [tile_start, tile_start + n_tiles) are those of round `round`
+// The tiles [tile_start, tile_start + n_tiles) are those of round `round`; `max_bits` is the largest width of
+// a page in the batch: the stream window of a wave is sized for a whole tile of bit-packed values of that width.
 extern "C" hipError_t pq2_launch_expand(const void *pages, const uint32_t *tile_page, uint32_t tile_start,
                                         uint32_t n_tiles, const void *resume, const uint32_t *run_pos, uint32_t round,
-                                        hipStream_t stream) {
+                                        uint32_t max_bits, hipStream_t stream) {
     if (n_tiles == 0) return hipSuccess;
-    hipLaunchKernelGGL(pq2::expand_kernel, dim3((n_tiles + 3u) / 4u), dim3(256), 0, stream,
+    uint32_t win_bytes = (pq2::kTileValues / 8u) * (max_bits ? max_bits : 1u) + 256u;
+    if (win_bytes < 2048u) win_bytes = 2048u;
+    // a workgroup gets at most 64 KiB: the widest pages then refill their window inside a tile
+    const uint32_t most = (65536u - 32u - 4u * (pq2::kTableRuns + 2u) * 8u - 4u * pq2::kChunkSlots * 4u) / 4u;
+    if (win_bytes > most) win_bytes = most;
+    win_bytes &= ~15u;
+    uint32_t pow2 = 2048u;
+    while (pow2 < win_bytes) pow2 <<= 1;
+    const uint32_t lds_bytes = 4u * win_bytes + 32u + 4u * (pq2::kTableRuns + 2u) * 8u + 4u * pq2::kChunkSlots * 4u;
+    hipLaunchKernelGGL(pq2::expand_kernel, dim3((n_tiles + 3u) / 4u), dim3(256), lds_bytes, stream,
                        (const pq2::PageDev *)pages, tile_page, (const pq2::Resume *)resume, run_pos, tile_start,
-                       tile_start + n_tiles, round);
+                       tile_start + n_tiles, round, win_bytes, pow2 * 8u - 1u);
     return hipGetLastError();
 }
 

@@ -45,6 +45,39 @@ KERNEL(k_min, "v_min_u32 %0, %0, %1", "v_min_u32 %1, %1, %2", "v_min_u32 %2, %2,
 KERNEL(k_mov_dpp, "v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf", "v_mov_b32_dpp %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf", "v_mov_b32_dpp %2, %3 row_shr:1 row_mask:0xf bank_mask:0xf", "v_mov_b32_dpp %3, %0 row_shr:1 row_mask:0xf bank_mask:0xf")
 KERNEL(k_sdwa, "v_and_b32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD", "v_and_b32_sdwa %1, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD", "v_and_b32_sdwa %2, %2, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD", "v_and_b32_sdwa %3, %3, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD")
 
+// scalar unit: `blockDim / 64` waves on one CU, each with 4 independent chains of s_add_u32 (or s_and / s_cmp+cselect)
+__global__ void k_salu(uint64_t *out, uint32_t x) {
+    uint32_t a = x, b = x + 1, c = x + 2, d = x + 3;
+    __syncthreads();
+    uint64_t t0 = __builtin_readcyclecounter();
+    for (int i = 0; i < REP; ++i)
+        asm volatile(
+            "s_add_u32 %0, %0, 3\n\ts_add_u32 %1, %1, 3\n\ts_add_u32 %2, %2, 3\n\ts_add_u32 %3, %3, 3\n\t"
+            "s_add_u32 %0, %0, 3\n\ts_add_u32 %1, %1, 3\n\ts_add_u32 %2, %2, 3\n\ts_add_u32 %3, %3, 3\n\t"
+            "s_add_u32 %0, %0, 3\n\ts_add_u32 %1, %1, 3\n\ts_add_u32 %2, %2, 3\n\ts_add_u32 %3, %3, 3\n\t"
+            "s_add_u32 %0, %0, 3\n\ts_add_u32 %1, %1, 3\n\ts_add_u32 %2, %2, 3\n\ts_add_u32 %3, %3, 3"
+            : "+s"(a), "+s"(b), "+s"(c), "+s"(d)::"scc");
+    uint64_t t1 = __builtin_readcyclecounter();
+    if ((threadIdx.x & 63) == 0) atomicMax((unsigned long long *)&out[0], (unsigned long long)(t1 - t0));
+    if (threadIdx.x == 0) out[1] = a + b + c + d;
+}
+// half scalar, half vector
+__global__ void k_mix(uint64_t *out, uint32_t x) {
+    uint32_t a = x, b = x + 1, c = x + threadIdx.x, d = x + 3 + threadIdx.x;
+    __syncthreads();
+    uint64_t t0 = __builtin_readcyclecounter();
+    for (int i = 0; i < REP; ++i)
+        asm volatile(
+            "s_add_u32 %0, %0, 3\n\tv_add_u32 %2, %2, 3\n\ts_add_u32 %1, %1, 3\n\tv_add_u32 %3, %3, 3\n\t"
+            "s_add_u32 %0, %0, 3\n\tv_add_u32 %2, %2, 3\n\ts_add_u32 %1, %1, 3\n\tv_add_u32 %3, %3, 3\n\t"
+            "s_add_u32 %0, %0, 3\n\tv_add_u32 %2, %2, 3\n\ts_add_u32 %1, %1, 3\n\tv_add_u32 %3, %3, 3\n\t"
+            "s_add_u32 %0, %0, 3\n\tv_add_u32 %2, %2, 3\n\ts_add_u32 %1, %1, 3\n\tv_add_u32 %3, %3, 3"
+            : "+s"(a), "+s"(b), "+v"(c), "+v"(d)::"scc");
+    uint64_t t1 = __builtin_readcyclecounter();
+    if ((threadIdx.x & 63) == 0) atomicMax((unsigned long long *)&out[0], (unsigned long long)(t1 - t0));
+    if (threadIdx.x == 0) out[1] = a + b + c + d;
+}
+
 #define RUN(k)                                                                                        \
     do {                                                                                              \
         hipLaunchKernelGGL(k, dim3(1), dim3(1024), 0, 0, d, 1u);                                      \
@@ -62,5 +95,17 @@ int main() {
     RUN(k_add); RUN(k_and); RUN(k_lshr); RUN(k_lshrv); RUN(k_bfe); RUN(k_bfev); RUN(k_alignbit); RUN(k_alignbitv);
     RUN(k_alignbyte); RUN(k_perm); RUN(k_lshr64); RUN(k_lshlor); RUN(k_andor); RUN(k_lshladd); RUN(k_add3);
     RUN(k_mul24); RUN(k_mad24); RUN(k_mullo); RUN(k_cndmask); RUN(k_cmp); RUN(k_min); RUN(k_mov_dpp); RUN(k_sdwa);
+    for (int waves = 4; waves <= 16; waves *= 2) {
+        for (int which = 0; which < 2; ++which) {
+            hipMemset(d, 0, 64);
+            if (which == 0) hipLaunchKernelGGL(k_salu, dim3(1), dim3(64 * waves), 0, 0, d, 1u);
+            else hipLaunchKernelGGL(k_mix, dim3(1), dim3(64 * waves), 0, 0, d, 1u);
+            hipDeviceSynchronize();
+            hipMemcpy(h, d, 32, hipMemcpyDeviceToHost);
+            printf("%s, %2d waves on one CU: %6.2f cycles per instruction per wave, %5.2f instructions per cycle on the CU\n",
+                   which == 0 ? "s_add_u32        " : "s_add + v_add mix", waves, (double)h[0] / (REP * 16.0),
+                   waves * REP * 16.0 / (double)h[0]);
+        }
+    }
     return 0;
 }

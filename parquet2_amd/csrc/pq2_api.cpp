@@ -20,7 +20,7 @@
 
 extern "C" {
 hipError_t pq2_launch_parse(const void *pages, uint32_t n_pages, void *resume, uint32_t *tile_page, uint32_t *run_pos,
-                            int32_t *status, void *state, uint32_t round, hipStream_t stream);
+                            int32_t *status, void *state, uint32_t round, uint32_t max_bits, hipStream_t stream);
 hipError_t pq2_launch_expand(const void *pages, const uint32_t *tile_page, uint32_t tile_start, uint32_t n_tiles,
                              const void *resume, const uint32_t *run_pos, uint32_t round, uint32_t max_bits,
                              hipStream_t stream);
@@ -280,7 +280,7 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
     for (uint32_t r = 0; r < rounds; ++r) {
         if ((st = stamped(false, ps, [&] {
                  return pq2_launch_parse(d_pages, static_cast<uint32_t>(n_pages), ctx->d_resume.ptr, d_tile_page,
-                                         d_run_pos, d_status, ctx->d_state.ptr, r, ps);
+                                         d_run_pos, d_status, ctx->d_state.ptr, r, max_bits, ps);
              })))
             return st;
         if (rounds > 1) {

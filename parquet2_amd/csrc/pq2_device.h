@@ -334,6 +334,16 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
     v += __builtin_amdgcn_update_dpp(0u, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
     return v;
 }
+// the sum with every partial result capped at `cap` (an associative operation on values <= cap < 2^31)
+__device__ __forceinline__ uint32_t wave_inclusive_sum_saturating(uint32_t v, uint32_t cap) {
+    v = min(v + (uint32_t)__builtin_amdgcn_update_dpp(0u, v, 0x111, 0xf, 0xf, false), cap);
+    v = min(v + (uint32_t)__builtin_amdgcn_update_dpp(0u, v, 0x112, 0xf, 0xf, false), cap);
+    v = min(v + (uint32_t)__builtin_amdgcn_update_dpp(0u, v, 0x114, 0xf, 0xf, false), cap);
+    v = min(v + (uint32_t)__builtin_amdgcn_update_dpp(0u, v, 0x118, 0xf, 0xf, false), cap);
+    v = min(v + (uint32_t)__builtin_amdgcn_update_dpp(0u, v, 0x142, 0xa, 0xf, false), cap);
+    v = min(v + (uint32_t)__builtin_amdgcn_update_dpp(0u, v, 0x143, 0xc, 0xf, false), cap);
+    return v;
+}
 __device__ __forceinline__ uint32_t wave_inclusive_max(uint32_t v) {
     v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0u, v, 0x111, 0xf, 0xf, false));
     v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0u, v, 0x112, 0xf, 0xf, false));

@@ -27,8 +27,12 @@
 
 namespace pq2 {
 
-constexpr uint32_t kHalf = 4096;    // bytes the stream window of parse_kernel advances by
-constexpr uint32_t kWin = 2 * kHalf;  // bytes of the window
+#ifndef PQ2_PARSE_HALF
+#define PQ2_PARSE_HALF 4096
+#endif
+constexpr uint32_t kHalf = PQ2_PARSE_HALF;      // bytes the stream window of parse_kernel advances by
+constexpr uint32_t kWin = 2 * kHalf;            // bytes of the window
+constexpr int kHalfPieces = (int)(kHalf / 1024u);  // dwordx4 loads of the wave per half
 
 // ---------------------------------------------------------------------------
 // parse_kernel
@@ -57,8 +61,57 @@ constexpr uint32_t kWin = 2 * kHalf;  // bytes of the window
 // the last needed one is looked at (and never reported: a header the reference
 // would not reach cannot fail the page).
 // ---------------------------------------------------------------------------
+// The chase loop of parse_kernel (see there).  HI_READ / HI_PARK: the instructions that move the second four
+// bytes behind a header into the record, or nothing.
+#define PQ2_CHASE(HI_READ, HI_PARK) \
+asm volatile( \
+                "s_mov_b64 %[exec_all], exec\n\t" \
+                "s_mov_b64 exec, 1\n\t" \
+                "s_sub_u32 %[m], %[m], 64\n\t" \
+                "v_add_u32 %[addr], %[pos], %[voff]\n\t" \
+                "ds_read_b64 v[2:3], %[addr]\n" \
+                "1:\n\t" \
+                "s_waitcnt lgkmcnt(0)\n\t" \
+                "v_readfirstlane_b32 %[lo], v2\n\t" \
+                "s_bfe_u32 %[groups], %[lo], 0x60001\n\t" \
+                "s_lshr_b32 %[t], %[lo], 2\n\t" \
+                "s_and_b32 %[t], %[t], 0x1fc0\n\t" \
+                "s_bitcmp1_b32 %[lo], 7\n\t" \
+                "s_cselect_b32 %[t], %[t], 0\n\t" \
+                "s_or_b32 %[groups], %[groups], %[t]\n\t" \
+                "s_mul_i32 %[bytes], %[groups], %[w]\n\t" \
+                "s_bitcmp1_b32 %[lo], 0\n\t" \
+                "s_cselect_b32 %[bytes], %[bytes], %[rb]\n\t" \
+                "s_bitcmp1_b32 %[lo], 7\n\t" \
+                "s_addc_u32 %[nm1], %[pos], %[bytes]\n\t" \
+                HI_READ \
+                "v_add_u32 %[addr], %[nm1], %[voff1]\n\t" \
+                "ds_read_b64 v[2:3], %[addr]\n\t" \
+                "s_mov_b32 m0, %[m]\n\t" \
+                "v_writelane_b32 %[r_pos], %[pos], m0\n\t" \
+                "v_writelane_b32 %[r_lo], %[lo], m0\n\t" \
+                HI_PARK \
+                "s_add_u32 %[pos], %[nm1], 1\n\t" \
+                "s_andn2_b32 %[t], 0x8080, %[lo]\n\t" \
+                "s_cselect_b32 %[chk], %[nm1], -1\n\t" \
+                "s_add_u32 %[m], %[m], 1\n\t" \
+                "s_cselect_b32 %[chk], -1, %[chk]\n\t" \
+                "s_cmp_le_u32 %[chk], %[limit]\n\t" \
+                "s_cbranch_scc1 1b\n\t" \
+                "s_waitcnt lgkmcnt(0)\n\t" \
+                "s_mov_b64 exec, %[exec_all]\n\t" \
+                "s_add_u32 %[m], %[m], 64" \
+                : [pos] "+s"(pos), [m] "+s"(m), [r_pos] "+v"(r_pos), [r_lo] "+v"(r_lo), [r_hi] "+v"(r_hi), \
+                  [lo] "=&s"(lo), [hi] "=&s"(hi), [groups] "=&s"(groups), [t] "=&s"(t), [bytes] "=&s"(bytes), \
+                  [nm1] "=&s"(nm1), [chk] "=&s"(chk), [addr] "=&v"(addr), [exec_all] "=&s"(exec_all) \
+                : [w] "s"(w), [rb] "s"(rb), [limit] "s"(min(end - 1u, win_lo + kWin - 9u)), [voff] "v"(voff), \
+                  [voff1] "v"(voff + 1u) \
+                : "v2", "v3", "scc", "memory");
+
 constexpr uint32_t kExplicit = 0x8080u;  // `lo` of a parked record that carries (kind, count, info) itself
 
+// kWide: some page of the batch is wider than 16 bits.
+template <bool kWide>
 __global__ __launch_bounds__(64) void parse_kernel(const PageDev *__restrict__ pages, uint32_t n_pages,
                                                    Resume *__restrict__ resume, uint32_t *__restrict__ tile_page,
                                                    uint32_t *__restrict__ run_pos, int32_t *__restrict__ status,
@@ -136,33 +189,33 @@ __global__ __launch_bounds__(64) void parse_kernel(const PageDev *__restrict__ p
     const uint32_t rb_mask = rb < 4 ? (1u << (rb * 8u)) - 1u : ~0u;  // the first min(4, rb) of them
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)win;
 
-    u32x4 pre[4];                              // prefetched half [win_lo + kWin, win_lo + kWin + kHalf)
+    u32x4 pre[kHalfPieces];                    // prefetched half [win_lo + kWin, win_lo + kWin + kHalf)
     uint32_t win_lo = ps.pos & ~(kHalf - 1u);  // a-offset (multiple of kHalf) of the first resident byte
 
     auto load_half = [&](uint32_t half_a, u32x4 *r) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < kHalfPieces; ++i)
             r[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, half_a + (uint32_t)i * 1024u + lane * 16u, 0, 0);
     };
     auto store_half = [&](uint32_t slot, const u32x4 *r) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *(u32x4 *)&win[slot + (uint32_t)i * 1024u + lane * 16u] = r[i];
+        for (int i = 0; i < kHalfPieces; ++i) *(u32x4 *)&win[slot + (uint32_t)i * 1024u + lane * 16u] = r[i];
     };
     // moves the window so that [at, at + 32) is resident; at >= win_lo + kHalf
     auto slide = [&](uint32_t at) {
         __syncthreads();  // every earlier window read of the wave is done before the window is overwritten
         if (at - win_lo + 32u <= kWin + kHalf) {
             // by one half: the upper half moves down, the prefetched half becomes the upper one
-            u32x4 up[4];
+            u32x4 up[kHalfPieces];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) up[i] = *(const u32x4 *)&win[kHalf + (uint32_t)i * 1024u + lane * 16u];
+            for (int i = 0; i < kHalfPieces; ++i) up[i] = *(const u32x4 *)&win[kHalf + (uint32_t)i * 1024u + lane * 16u];
             store_half(0, up);
             store_half(kHalf, pre);
             win_lo += kHalf;
         } else {
             // a run that jumped beyond the prefetched half
             win_lo = at & ~(kHalf - 1);
-            u32x4 a[4], b[4];
+            u32x4 a[kHalfPieces], b[kHalfPieces];
             load_half(win_lo, a);
             load_half(win_lo + kHalf, b);
             store_half(0, a);
@@ -177,7 +230,7 @@ __global__ __launch_bounds__(64) void parse_kernel(const PageDev *__restrict__ p
     };
 
     {  // first window
-        u32x4 a[4], b[4];
+        u32x4 a[kHalfPieces], b[kHalfPieces];
         load_half(win_lo, a);
         load_half(win_lo + kHalf, b);
         load_half(win_lo + kWin, pre);
@@ -204,49 +257,12 @@ __global__ __launch_bounds__(64) void parse_kernel(const PageDev *__restrict__ p
             uint32_t lo, hi, groups, t, bytes, nm1, chk, addr;  // nm1: the next header's position minus one
             uint64_t exec_all;
             const uint32_t voff = lds_base - win_lo;
-            asm volatile(
-                "s_mov_b64 %[exec_all], exec\n\t"
-                "s_mov_b64 exec, 1\n\t"
-                "s_sub_u32 %[m], %[m], 64\n\t"
-                "v_add_u32 %[addr], %[pos], %[voff]\n\t"
-                "ds_read_b64 v[2:3], %[addr]\n"
-                "1:\n\t"
-                "s_waitcnt lgkmcnt(0)\n\t"
-                "v_readfirstlane_b32 %[lo], v2\n\t"
-                "s_bfe_u32 %[groups], %[lo], 0x60001\n\t"
-                "s_lshr_b32 %[t], %[lo], 2\n\t"
-                "s_and_b32 %[t], %[t], 0x1fc0\n\t"
-                "s_bitcmp1_b32 %[lo], 7\n\t"
-                "s_cselect_b32 %[t], %[t], 0\n\t"
-                "s_or_b32 %[groups], %[groups], %[t]\n\t"
-                "s_mul_i32 %[bytes], %[groups], %[w]\n\t"
-                "s_bitcmp1_b32 %[lo], 0\n\t"
-                "s_cselect_b32 %[bytes], %[bytes], %[rb]\n\t"
-                "s_bitcmp1_b32 %[lo], 7\n\t"
-                "s_addc_u32 %[nm1], %[pos], %[bytes]\n\t"
-                "v_readfirstlane_b32 %[hi], v3\n\t"
-                "v_add_u32 %[addr], %[nm1], %[voff1]\n\t"
-                "ds_read_b64 v[2:3], %[addr]\n\t"
-                "s_mov_b32 m0, %[m]\n\t"
-                "v_writelane_b32 %[r_pos], %[pos], m0\n\t"
-                "v_writelane_b32 %[r_lo], %[lo], m0\n\t"
-                "v_writelane_b32 %[r_hi], %[hi], m0\n\t"
-                "s_add_u32 %[pos], %[nm1], 1\n\t"
-                "s_andn2_b32 %[t], 0x8080, %[lo]\n\t"
-                "s_cselect_b32 %[chk], %[nm1], -1\n\t"
-                "s_add_u32 %[m], %[m], 1\n\t"
-                "s_cselect_b32 %[chk], -1, %[chk]\n\t"
-                "s_cmp_le_u32 %[chk], %[limit]\n\t"
-                "s_cbranch_scc1 1b\n\t"
-                "s_waitcnt lgkmcnt(0)\n\t"
-                "s_mov_b64 exec, %[exec_all]\n\t"
-                "s_add_u32 %[m], %[m], 64"
-                : [pos] "+s"(pos), [m] "+s"(m), [r_pos] "+v"(r_pos), [r_lo] "+v"(r_lo), [r_hi] "+v"(r_hi),
-                  [lo] "=&s"(lo), [hi] "=&s"(hi), [groups] "=&s"(groups), [t] "=&s"(t), [bytes] "=&s"(bytes),
-                  [nm1] "=&s"(nm1), [chk] "=&s"(chk), [addr] "=&v"(addr), [exec_all] "=&s"(exec_all)
-                : [w] "s"(w), [rb] "s"(rb), [limit] "s"(min(end - 1u, win_lo + kWin - 9u)), [voff] "v"(voff),
-                  [voff1] "v"(voff + 1u)
-                : "v2", "v3", "scc", "memory");
+            // the bytes behind the header's first four are only needed for RLE values of more than two bytes
+            if constexpr (kWide) {
+                PQ2_CHASE("v_readfirstlane_b32 %[hi], v3\n\t", "v_writelane_b32 %[r_hi], %[hi], m0\n\t")
+            } else {
+                PQ2_CHASE("", "")
+            }
             if ((~lo & kExplicit) == 0u || nm1 > end - 1u) {
                 // three or more header bytes, a run cut by the end of the stream, or the end itself: the record
                 // parked last does not count
@@ -298,14 +314,9 @@ __global__ __launch_bounds__(64) void parse_kernel(const PageDev *__restrict__ p
         }
         const uint32_t left = n - produced;  // > 0
         const uint32_t cnt = (lane < m && kind < kEnd) ? min(count, left) : 0u;
-        uint32_t incl = cnt;  // inclusive prefix sum, saturating at `left` (all terms <= left < 2^31)
-#pragma unroll
-        for (uint32_t d = 1; d < 64; d <<= 1) {
-            const uint32_t up = __shfl_up(incl, d, 64);
-            if (lane >= d) incl = min(incl + up, left);
-        }
-        uint32_t before = __shfl_up(incl, 1, 64);
-        if (lane == 0) before = 0;
+        // inclusive prefix sum, saturating at `left` (all terms <= left < 2^31, so no step overflows)
+        const uint32_t incl = wave_inclusive_sum_saturating(cnt, left);
+        const uint32_t before = __builtin_amdgcn_update_dpp(0u, incl, 0x138, 0xf, 0xf, false);  // wave_shr:1
         const uint32_t eff = min(cnt, left - before);  // the page ends inside or before this run: mod.rs:76-78
         const bool yields = eff > 0u;
         const uint64_t ymask = __ballot(yields);
@@ -778,10 +789,14 @@ __global__ __launch_bounds__(256) void bitunpack_kernel(uint64_t in_addr, uint32
 // ---- launchers (called from pq2_api.cpp) ----------------------------------------
 extern "C" hipError_t pq2_launch_parse(const void *pages, uint32_t n_pages, void *resume, uint32_t *tile_page,
                                        uint32_t *run_pos, int32_t *status, void *state, uint32_t round,
-                                       hipStream_t stream) {
+                                       uint32_t max_bits, hipStream_t stream) {
     if (n_pages == 0) return hipSuccess;
-    hipLaunchKernelGGL(pq2::parse_kernel, dim3(n_pages), dim3(64), 0, stream, (const pq2::PageDev *)pages, n_pages,
-                       (pq2::Resume *)resume, tile_page, run_pos, status, (pq2::ParseState *)state, round);
+    if (max_bits > 16u)
+        hipLaunchKernelGGL(pq2::parse_kernel<true>, dim3(n_pages), dim3(64), 0, stream, (const pq2::PageDev *)pages,
+                           n_pages, (pq2::Resume *)resume, tile_page, run_pos, status, (pq2::ParseState *)state, round);
+    else
+        hipLaunchKernelGGL(pq2::parse_kernel<false>, dim3(n_pages), dim3(64), 0, stream, (const pq2::PageDev *)pages,
+                           n_pages, (pq2::Resume *)resume, tile_page, run_pos, status, (pq2::ParseState *)state, round);
     return hipGetLastError();
 }
 

@@ -41,6 +41,9 @@ def parse_args():
     ap.add_argument("--distinct", type=int, default=16, help="distinct generated pages (replicated on the device)")
     ap.add_argument("--workload", default="dict", choices=["dict", "def", "adversarial", "bitpacked"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-path", action="store_true",
+                    help="time pq2_decode_batch_host instead (page-locked host buffers in, host buffers out: the "
+                         "copies over PCIe are inside the timed region); prints its own JSON line")
     ap.add_argument("--no-parity", action="store_true",
                     help="skip the parity gate (only for timing experiments with builds that write no results)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -169,6 +172,30 @@ def main():
 
     ctx = Context(local_rank)
     stream = torch.cuda.current_stream().cuda_stream
+
+    if args.host_path:  # end to end, host memory to host memory
+        h_in_t = torch.empty(d_in.numel(), dtype=torch.uint8, pin_memory=True)
+        h_in_t.copy_(d_in.reshape(-1).cpu())
+        h_out_t = torch.zeros(my_pages * n, dtype=torch.int32, pin_memory=True)
+        h_in_np, h_out_np = h_in_t.numpy(), h_out_t.numpy().view(np.uint32)
+        ctx.decode_batch_host(h_in_np, descs, my_pages * n, out=h_out_np)
+        for i in range(min(my_pages, len(pages))):
+            assert np.array_equal(h_out_np[i * n:(i + 1) * n], pages[(lo + i) % len(pages)][1]), "host path differs"
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            _, status = ctx.decode_batch_host(h_in_np, descs, my_pages * n, out=h_out_np)
+        elapsed = time.perf_counter() - t0
+        assert (status == 0).all()
+        print(json.dumps({
+            "metric": "host-to-host hybrid-RLE/bitpack decode GB/s (output bytes), copies included",
+            "value": round(out_bytes * args.steps / elapsed / 1e9, 2), "unit": "GB/s", "n_gpus": 1,
+            "steps": args.steps, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "bytes_over_pcie_per_step": int(d_in.numel()) + out_bytes,
+            "pcie_gbs": round((d_in.numel() + out_bytes) * args.steps / elapsed / 1e9, 2),
+            "config": {"workload": "%s: %d pages x %d values, bit width %d, page-locked host buffers" %
+                       (args.workload, my_pages, n, bits)}}), flush=True)
+        ctx.close()
+        return
 
     def step(want_status=False):
         return ctx.decode_batch_device(d_in.data_ptr(), d_in.numel(), descs, d_out.data_ptr(), my_pages * n, stream,

@@ -111,8 +111,11 @@ int32_t pq2_decode_batch_device(pq2_ctx *ctx, const void *d_in, uint64_t in_byte
 int32_t pq2_fetch_status(pq2_ctx *ctx, int32_t *status, uint64_t n_pages);
 
 /* Same contract with host buffers: copies the streams to the GPU, decodes,
- * copies the values back (in page-aligned chunks on three streams, so copies
- * and kernels overlap).  This is what a per-page drop-in of
+ * copies the values back.  Batches of 32 MiB and more (input + output) go in
+ * chunks of whole pages, about 16 Mi values each, through three internal
+ * streams, so that the upload of one chunk, the kernels of another and the
+ * download of a third overlap (the copies are asynchronous only from and to
+ * page-locked host memory).  This is what a per-page drop-in of
  * HybridRleDecoder / deserialize::utils::dict_indices_decoder
  * (src/deserialize/utils.rs:13-27) calls. */
 int32_t pq2_decode_batch_host(pq2_ctx *ctx, const void *h_in, uint64_t in_bytes, const pq2_page_desc *descs,

@@ -170,13 +170,16 @@ class Context:
         return status
 
     # ---- host-buffer batch decode -------------------------------------------
-    def decode_batch_host(self, data, descs, out_values=None):
-        """Returns (values ndarray of uint32, statuses ndarray of int32)."""
+    def decode_batch_host(self, data, descs, out_values=None, out=None):
+        """Returns (values ndarray of uint32, statuses ndarray of int32).  `out`: a uint32 array to decode into
+        (page-locked memory lets the copies of the chunks overlap)."""
         data = as_u8(data)
         descs = np.ascontiguousarray(descs, dtype=PAGE_DESC_DTYPE)
         if out_values is None:
             out_values = int((descs["out_off"] + descs["num_values"]).max()) if len(descs) else 0
-        out = np.zeros(out_values, dtype=np.uint32)
+        if out is None:
+            out = np.zeros(out_values, dtype=np.uint32)
+        assert out.dtype == np.uint32 and out.flags.c_contiguous and out.size >= out_values
         status = np.zeros(len(descs), dtype=np.int32)
         st = lib().pq2_decode_batch_host(self._h, ptr(data), data.size, ptr(descs), len(descs), ptr(out), out_values,
                                          ptr(status))

@@ -14,6 +14,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/pq2hip.h"
@@ -89,10 +90,11 @@ struct pq2_ctx {
     };
     std::vector<Stamp> stamps;
     uint64_t stamped_batches = 0;
-    // host-buffer path
+    // host-buffer path: device arenas; large batches go in chunks through three lanes (child contexts with a
+    // stream each), so that the upload of one chunk, the kernels of another and the download of a third overlap
     DevBuf d_in, d_out;
-    hipStream_t copy_streams[3] = {nullptr, nullptr, nullptr};
-    hipEvent_t chunk_done[3] = {nullptr, nullptr, nullptr};
+    pq2_ctx *lanes[3] = {nullptr, nullptr, nullptr};
+    hipStream_t lane_stream = nullptr;  // of a child context
 };
 
 namespace {
@@ -366,10 +368,9 @@ int32_t pq2_ctx_destroy(pq2_ctx *ctx) {
         (void)hipEventDestroy(s.begin);
         (void)hipEventDestroy(s.end);
     }
-    for (int i = 0; i < 3; ++i) {
-        if (ctx->copy_streams[i]) (void)hipStreamDestroy(ctx->copy_streams[i]);
-        if (ctx->chunk_done[i]) (void)hipEventDestroy(ctx->chunk_done[i]);
-    }
+    for (pq2_ctx *lane : ctx->lanes)
+        if (lane) (void)pq2_ctx_destroy(lane);
+    if (ctx->lane_stream) (void)hipStreamDestroy(ctx->lane_stream);
     delete ctx;
     return PQ2_OK;
 }
@@ -438,31 +439,149 @@ int32_t pq2_fetch_status(pq2_ctx *ctx, int32_t *status, uint64_t n_pages) {
     return fetch_status(ctx, status, n_pages);
 }
 
+}  // extern "C"
+
+namespace {
+
+constexpr uint64_t kChunkValues = 16ull << 20;       // a chunk of the host path ends once it holds this many values
+constexpr uint64_t kSingleShotBytes = 32ull << 20;   // batches below this go through in one piece
+
+// One chunk of a host batch through one lane: upload of the byte range its pages span, decode, download of the
+// value ranges its pages cover (adjacent pages in one copy), statuses.  Everything is enqueued on the lane's stream.
+int32_t enqueue_host_chunk(pq2_ctx *ctx, pq2_ctx *lane, const uint8_t *h_in, const pq2_page_desc *descs, uint64_t first,
+                           uint64_t last, uint32_t *h_out, int32_t *status, std::vector<pq2_page_desc> &scratch,
+                           std::vector<std::pair<uint64_t, int32_t>> &overrides) {
+    uint64_t in_lo = ~0ull, in_hi = 0, out_lo = ~0ull, out_hi = 0;
+    for (uint64_t i = first; i < last; ++i) {
+        const pq2_page_desc &d = descs[i];
+        if (d.num_values == 0) continue;
+        out_lo = std::min(out_lo, d.out_off);
+        out_hi = std::max(out_hi, d.out_off + d.num_values);
+        if (d.in_len == 0) continue;
+        in_lo = std::min(in_lo, d.in_off);
+        in_hi = std::max(in_hi, d.in_off + d.in_len);
+    }
+    if (in_hi <= in_lo) in_lo = in_hi = 0;
+    if (out_hi <= out_lo) out_lo = out_hi = 0;
+    scratch.assign(descs + first, descs + last);
+    for (pq2_page_desc &d : scratch) {
+        d.in_off = (d.in_len == 0 || d.num_values == 0) ? 0 : d.in_off - in_lo;
+        if (d.num_values == 0) d.in_len = 0;
+        d.out_off = d.num_values == 0 ? 0 : d.out_off - out_lo;
+    }
+    hipStream_t s = lane->lane_stream;
+    // the lane's arenas and metadata are reused: its previous chunk has to be through
+    PQ2_HIP(ctx, hipStreamSynchronize(s));
+    int32_t st;
+    // +16: the kernels read whole aligned dwords, never beyond the 16-byte line of the last stream byte
+    if ((st = reserve(ctx, lane->d_in, in_hi - in_lo + 16))) return st;
+    if ((st = reserve(ctx, lane->d_out, std::max<uint64_t>(out_hi - out_lo, 1) * sizeof(uint32_t)))) return st;
+    if (in_hi > in_lo) PQ2_HIP(ctx, hipMemcpyAsync(lane->d_in.ptr, h_in + in_lo, in_hi - in_lo, hipMemcpyHostToDevice, s));
+    st = enqueue_batch(lane, lane->d_in.ptr, in_hi - in_lo, scratch.data(), last - first,
+                       static_cast<uint32_t *>(lane->d_out.ptr), out_hi - out_lo, s);
+    if (st != PQ2_OK) {
+        ctx->last_error = lane->last_error;
+        return st;
+    }
+    // values back: one copy per maximal range of pages that follow each other in the output
+    uint64_t run_lo = 0, run_hi = 0;
+    auto flush = [&]() -> int32_t {
+        if (run_hi > run_lo)
+            PQ2_HIP(ctx, hipMemcpyAsync(h_out + run_lo, static_cast<uint32_t *>(lane->d_out.ptr) + (run_lo - out_lo),
+                                        (run_hi - run_lo) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        return PQ2_OK;
+    };
+    for (uint64_t i = first; i < last; ++i) {
+        const pq2_page_desc &d = descs[i];
+        if (d.num_values == 0) continue;
+        if (d.out_off == run_hi && run_hi > run_lo) {
+            run_hi += d.num_values;
+        } else {
+            if ((st = flush())) return st;
+            run_lo = d.out_off;
+            run_hi = d.out_off + d.num_values;
+        }
+    }
+    if ((st = flush())) return st;
+    if (status) {
+        PQ2_HIP(ctx, hipMemcpyAsync(status + first, lane->d_status.ptr, (last - first) * sizeof(int32_t),
+                                    hipMemcpyDeviceToHost, s));
+        for (uint64_t i = first; i < last; ++i)
+            if (lane->host_status[i - first] != PQ2_OK) overrides.emplace_back(i, lane->host_status[i - first]);
+    }
+    return PQ2_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
 int32_t pq2_decode_batch_host(pq2_ctx *ctx, const void *h_in, uint64_t in_bytes, const pq2_page_desc *descs,
                               uint64_t n_pages, uint32_t *h_out, uint64_t out_values, int32_t *status) {
     if (!ctx) return PQ2_INVALID_PARAMETER;
     PQ2_HIP(ctx, hipSetDevice(ctx->device));
     int32_t st;
-    // +16: the kernels read whole aligned dwords, never beyond the 16-byte line of the last stream byte
-    if ((st = reserve(ctx, ctx->d_in, in_bytes + 16))) return st;
-    if ((st = reserve(ctx, ctx->d_out, std::max<uint64_t>(out_values, 1) * sizeof(uint32_t)))) return st;
-    hipStream_t s = nullptr;
-    PQ2_HIP(ctx, hipMemcpyAsync(ctx->d_in.ptr, h_in, in_bytes, hipMemcpyHostToDevice, s));
-    st = enqueue_batch(ctx, ctx->d_in.ptr, in_bytes, descs, n_pages, static_cast<uint32_t *>(ctx->d_out.ptr), out_values,
-                       s);
-    if (st != PQ2_OK) return st;
-    // only the ranges the pages cover are defined; copy the covering span back
-    uint64_t lo = out_values, hi = 0;
-    for (uint64_t i = 0; i < n_pages; ++i) {
-        if (descs[i].num_values == 0) continue;
-        lo = std::min(lo, descs[i].out_off);
-        hi = std::max(hi, descs[i].out_off + descs[i].num_values);
+    uint64_t total_values = 0;
+    for (uint64_t i = 0; i < n_pages; ++i) total_values += descs ? descs[i].num_values : 0;
+    if (in_bytes + total_values * sizeof(uint32_t) < kSingleShotBytes) {
+        // +16: the kernels read whole aligned dwords, never beyond the 16-byte line of the last stream byte
+        if ((st = reserve(ctx, ctx->d_in, in_bytes + 16))) return st;
+        if ((st = reserve(ctx, ctx->d_out, std::max<uint64_t>(out_values, 1) * sizeof(uint32_t)))) return st;
+        hipStream_t s = nullptr;
+        PQ2_HIP(ctx, hipMemcpyAsync(ctx->d_in.ptr, h_in, in_bytes, hipMemcpyHostToDevice, s));
+        st = enqueue_batch(ctx, ctx->d_in.ptr, in_bytes, descs, n_pages, static_cast<uint32_t *>(ctx->d_out.ptr),
+                           out_values, s);
+        if (st != PQ2_OK) return st;
+        // only the ranges the pages cover are defined; copy the covering span back
+        uint64_t lo = out_values, hi = 0;
+        for (uint64_t i = 0; i < n_pages; ++i) {
+            if (descs[i].num_values == 0) continue;
+            lo = std::min(lo, descs[i].out_off);
+            hi = std::max(hi, descs[i].out_off + descs[i].num_values);
+        }
+        if (hi > lo)
+            PQ2_HIP(ctx, hipMemcpyAsync(h_out + lo, static_cast<uint32_t *>(ctx->d_out.ptr) + lo,
+                                        (hi - lo) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        if (status) return fetch_status(ctx, status, n_pages);
+        PQ2_HIP(ctx, hipStreamSynchronize(s));
+        return PQ2_OK;
     }
-    if (hi > lo)
-        PQ2_HIP(ctx, hipMemcpyAsync(h_out + lo, static_cast<uint32_t *>(ctx->d_out.ptr) + lo,
-                                    (hi - lo) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    if (status) return fetch_status(ctx, status, n_pages);
-    PQ2_HIP(ctx, hipStreamSynchronize(s));
+
+    // the same checks as the device entry point, against the caller's buffers, before any chunk is started
+    for (uint64_t i = 0; i < n_pages; ++i) {
+        const pq2_page_desc &d = descs[i];
+        if (d.in_len > PQ2_MAX_PAGE_BYTES) return fail(ctx, PQ2_INVALID_PARAMETER, "page stream too long");
+        if (d.in_off > in_bytes || d.in_len > in_bytes - d.in_off)
+            return fail(ctx, PQ2_INVALID_PARAMETER, "page stream outside the input buffer");
+        if (d.num_values > PQ2_MAX_PAGE_VALUES) return fail(ctx, PQ2_INVALID_PARAMETER, "page has too many values");
+        if (d.out_off > out_values || d.num_values > out_values - d.out_off)
+            return fail(ctx, PQ2_INVALID_PARAMETER, "page output outside the output buffer");
+    }
+    for (pq2_ctx *&lane : ctx->lanes) {
+        if (lane) continue;
+        if ((st = pq2_ctx_create(ctx->device, &lane))) return fail(ctx, st, "cannot create a lane of the host path");
+        lane->profiling = false;
+        PQ2_HIP(ctx, hipStreamCreateWithFlags(&lane->lane_stream, hipStreamNonBlocking));
+    }
+    std::vector<pq2_page_desc> scratch;
+    std::vector<std::pair<uint64_t, int32_t>> overrides;
+    uint64_t first = 0, chunk = 0;
+    st = PQ2_OK;
+    while (first < n_pages && st == PQ2_OK) {
+        uint64_t last = first, values = 0;
+        while (last < n_pages && (values < kChunkValues || last == first)) values += descs[last++].num_values;
+        st = enqueue_host_chunk(ctx, ctx->lanes[chunk % 3], static_cast<const uint8_t *>(h_in), descs, first, last, h_out,
+                                status, scratch, overrides);
+        first = last;
+        ++chunk;
+    }
+    for (pq2_ctx *lane : ctx->lanes) {
+        const hipError_t e = hipStreamSynchronize(lane->lane_stream);
+        if (e != hipSuccess && st == PQ2_OK) st = hip_fail(ctx, e, "hipStreamSynchronize");
+    }
+    if (st != PQ2_OK) return st;
+    for (const auto &o : overrides) status[o.first] = o.second;
+    ctx->last_n_pages = 0;  // the statuses were delivered with the call
     return PQ2_OK;
 }
 

@@ -401,3 +401,38 @@ def test_idempotent_and_checksum_at_scale(ctx, oracle):
     view = d_out.view(reps, len(pages), n)
     assert all(torch.equal(view[0], view[r]) for r in range(1, reps))
     assert (view[0, 2].cpu().numpy().view(np.uint32) == pages[2][1]).all()
+
+
+def test_host_path_in_chunks(ctx, oracle):
+    """A batch above the single-shot size goes through the three lanes of the host path in chunks of whole pages:
+    ragged pages, empty pages, gaps between the outputs (which must stay untouched) and a page that panics."""
+    rng = np.random.default_rng(5)
+    batch = synth.PageBatch(align=1)
+    expect = []
+    for i in range(90):
+        w = int(rng.integers(1, 21))
+        n = 0 if i % 17 == 5 else int(rng.integers(100_000, 700_000))
+        if i == 40:  # an RLE run with one of its two value bytes (decoder.rs:59-60)
+            w, stream, vals = 12, np.array([16, 7], dtype=np.uint8), None
+        else:
+            stream, vals = synth.dict_page(synth.seed_for(7, i), n, w, mean_repeat=40.0, mean_distinct=300.0)
+        batch.add(stream, w, n, out_align=int(rng.integers(1, 9)))
+        expect.append(vals)
+    data, descs, out_values = batch.finish()
+    assert data.size + 4 * out_values > (64 << 20)
+    got, status = ctx.decode_batch_host(data, descs, out_values)
+    covered = np.zeros(out_values, dtype=bool)
+    for i, vals in enumerate(expect):
+        o, n = int(descs[i]["out_off"]), int(descs[i]["num_values"])
+        if vals is None:
+            assert status[i] == REFERENCE_WOULD_PANIC
+        else:
+            assert status[i] == OK
+            assert (got[o:o + n] == vals).all(), i
+        covered[o:o + n] = True
+    assert (got[~covered] == 0).all()  # the host buffer between the pages is not written
+    # spot-check the generator against the oracle on one page of the batch
+    i = 3
+    st_o, exp = oracle.hybrid_rle_decode(data[int(descs[i]["in_off"]):int(descs[i]["in_off"]) + int(descs[i]["in_len"])],
+                                         int(descs[i]["num_bits"]), int(descs[i]["num_values"]))
+    assert st_o == OK and (exp == expect[i]).all()

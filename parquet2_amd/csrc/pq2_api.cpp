@@ -94,6 +94,8 @@ struct pq2_ctx {
     // stream each), so that the upload of one chunk, the kernels of another and the download of a third overlap
     DevBuf d_in, d_out;
     pq2_ctx *lanes[3] = {nullptr, nullptr, nullptr};
+    int32_t *h_status = nullptr;  // page-locked: a copy into the caller's (pageable) array would block every chunk
+    size_t h_status_cap = 0;
     hipStream_t lane_stream = nullptr;  // of a child context
 };
 
@@ -370,6 +372,7 @@ int32_t pq2_ctx_destroy(pq2_ctx *ctx) {
     }
     for (pq2_ctx *lane : ctx->lanes)
         if (lane) (void)pq2_ctx_destroy(lane);
+    if (ctx->h_status) (void)hipHostFree(ctx->h_status);
     if (ctx->lane_stream) (void)hipStreamDestroy(ctx->lane_stream);
     delete ctx;
     return PQ2_OK;
@@ -504,7 +507,7 @@ int32_t enqueue_host_chunk(pq2_ctx *ctx, pq2_ctx *lane, const uint8_t *h_in, con
     }
     if ((st = flush())) return st;
     if (status) {
-        PQ2_HIP(ctx, hipMemcpyAsync(status + first, lane->d_status.ptr, (last - first) * sizeof(int32_t),
+        PQ2_HIP(ctx, hipMemcpyAsync(ctx->h_status + first, lane->d_status.ptr, (last - first) * sizeof(int32_t),
                                     hipMemcpyDeviceToHost, s));
         for (uint64_t i = first; i < last; ++i)
             if (lane->host_status[i - first] != PQ2_OK) overrides.emplace_back(i, lane->host_status[i - first]);
@@ -563,6 +566,14 @@ int32_t pq2_decode_batch_host(pq2_ctx *ctx, const void *h_in, uint64_t in_bytes,
         lane->profiling = false;
         PQ2_HIP(ctx, hipStreamCreateWithFlags(&lane->lane_stream, hipStreamNonBlocking));
     }
+    if (status && ctx->h_status_cap < n_pages) {
+        if (ctx->h_status) PQ2_HIP(ctx, hipHostFree(ctx->h_status));
+        ctx->h_status = nullptr;
+        ctx->h_status_cap = 0;
+        PQ2_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_status), n_pages * sizeof(int32_t),
+                                   hipHostMallocDefault));
+        ctx->h_status_cap = n_pages;
+    }
     std::vector<pq2_page_desc> scratch;
     std::vector<std::pair<uint64_t, int32_t>> overrides;
     uint64_t first = 0, chunk = 0;
@@ -580,6 +591,7 @@ int32_t pq2_decode_batch_host(pq2_ctx *ctx, const void *h_in, uint64_t in_bytes,
         if (e != hipSuccess && st == PQ2_OK) st = hip_fail(ctx, e, "hipStreamSynchronize");
     }
     if (st != PQ2_OK) return st;
+    if (status) std::memcpy(status, ctx->h_status, n_pages * sizeof(int32_t));
     for (const auto &o : overrides) status[o.first] = o.second;
     ctx->last_n_pages = 0;  // the statuses were delivered with the call
     return PQ2_OK;

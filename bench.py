@@ -250,6 +250,17 @@ def main():
         expand_avg_ms = expand_ms / max(expand_launches, 1)
         bytes_per_launch = (in_bytes_alg + out_bytes) / rounds
         achieved = bytes_per_launch / (expand_avg_ms * 1e-3) / 1e9
+        # HBM bytes of expand_kernel from the PMC passes recorded for this workload (FETCH_SIZE / WRITE_SIZE cannot be
+        # collected from inside the process)
+        traffic = None
+        try:
+            t = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_traffic.json")))
+            if t["workload"] == {"workload": args.workload, "pages_per_gpu": args.pages, "values_per_page": n,
+                                 "num_bits": bits}:
+                e = t["expand_kernel"]
+                traffic = (e["fetch_bytes_per_step"] + e["write_bytes_per_step"]) // rounds
+        except (OSError, KeyError, ValueError):
+            pass
         result = {
             "metric": METRIC, "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
@@ -265,7 +276,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "kernel": "expand_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": int(bytes_per_launch),
                 "avg_launch_ms": round(expand_avg_ms, 4), "launches_per_step": rounds,
                 "parse_kernel_ms_per_step": round(parse_ms / max(batches, 1), 4),

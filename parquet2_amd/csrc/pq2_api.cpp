@@ -27,6 +27,9 @@ hipError_t pq2_launch_expand(const void *pages, const uint32_t *tile_page, uint3
                              hipStream_t stream);
 hipError_t pq2_launch_bitunpack(const void *d_packed, uint32_t packed_len, uint32_t num_bits, uint32_t length,
                                 uint32_t *d_out, hipStream_t stream);
+hipError_t pq2_launch_decode(const void *pages, uint32_t n_pages, void *resume, uint32_t *run_pos, int32_t *status,
+                             void *state, uint32_t *cu_tickets, uint32_t max_bits, hipStream_t stream);
+uint32_t pq2_cu_ticket_bytes();
 }
 
 namespace {
@@ -36,6 +39,7 @@ constexpr uint32_t kBlocksPerTile = 4;
 constexpr uint32_t kRounds = 4;          // must match pq2::kRounds
 constexpr uint64_t kMinRoundedTiles = 16384;  // batches below 64 Mi values are decoded in one round
 constexpr size_t kParseStateBytes = 16;  // sizeof(pq2::ParseState)
+constexpr uint64_t kFusedMinPages = 64;  // batches of at least this many pages take one workgroup per page
 
 struct PageDev {  // must match pq2::PageDev
     uint64_t in_addr;
@@ -66,12 +70,18 @@ struct pq2_ctx {
     hipEvent_t meta_copied = nullptr;  // the previous upload has left h_meta
     bool meta_in_flight = false;
     DevBuf d_meta, d_status, d_resume, d_tile_page, d_run_pos, d_state;
+    DevBuf d_tickets;  // decode_kernel's per-compute-unit counters (zeroed once; only their low bits matter)
     // Where the rounds of a page end, as fractions of its tiles (the last round ends with the page).  The parts
     // grow because round r + 1 is parsed while round r is expanded, and parsing is the faster of the two; the
     // first part is small because nothing hides its parse.  Tuning knobs: PQ2_ROUND_SPLIT="a,b,c",
     // PQ2_MIN_ROUNDED_TILES.
     double round_split[kRounds - 1] = {0.25, 1.0, 1.0};
     uint64_t min_rounded_tiles = kMinRoundedTiles;
+    // How a batch is scheduled.  kPerPage: decode_kernel, one workgroup per page, the header walk and the
+    // expansion of a page side by side (batches with enough pages to fill the GPU that way).  kPerTile:
+    // parse_kernel + expand_kernel, one wave per 4096 values, in rounds (few, large pages).  PQ2_MODE=page|tile
+    // forces one of them.
+    enum Mode { kAuto, kPerPage, kPerTile } mode = kAuto;
     // rounds: parse_kernel of round r + 1 runs on parse_stream while expand_kernel of round r runs on expand_stream
     // (two of them, taken in turn: the expand launches of one batch do not depend on each other, so the next one
     // starts while the last waves of the previous one drain)
@@ -199,8 +209,9 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
     }
     if ((reinterpret_cast<uintptr_t>(d_out) & 3u) != 0) return fail(ctx, PQ2_INVALID_PARAMETER, "d_out misaligned");
 
+    const bool per_page = ctx->mode == pq2_ctx::kPerPage || (ctx->mode == pq2_ctx::kAuto && n_pages >= kFusedMinPages);
     // tiles are numbered round-major: all tiles of round 0 of all pages, then round 1, ...
-    const bool split = tiles >= ctx->min_rounded_tiles;
+    const bool split = !per_page && tiles >= ctx->min_rounded_tiles;
     uint64_t round_start[kRounds + 1] = {0};
     for (uint64_t i = 0; i < n_pages; ++i) {
         PageDev &p = pages[i];
@@ -235,7 +246,7 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
     if ((st = reserve(ctx, ctx->d_status, n_pages * sizeof(int32_t)))) return st;
     if ((st = reserve(ctx, ctx->d_state, n_pages * kParseStateBytes))) return st;
     if ((st = reserve(ctx, ctx->d_resume, std::max<uint64_t>(tiles, 1) * kBlocksPerTile * 16))) return st;
-    if ((st = reserve(ctx, ctx->d_tile_page, std::max<uint64_t>(tiles, 1) * sizeof(uint32_t)))) return st;
+    if (!per_page && (st = reserve(ctx, ctx->d_tile_page, std::max<uint64_t>(tiles, 1) * sizeof(uint32_t)))) return st;
     if ((st = reserve(ctx, ctx->d_run_pos, std::max<uint64_t>(run_entries, 1) * sizeof(uint32_t)))) return st;
 
     PQ2_HIP(ctx, hipMemcpyAsync(ctx->d_meta.ptr, ctx->h_meta, meta_bytes, hipMemcpyHostToDevice, stream));
@@ -281,6 +292,19 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
         }
         return PQ2_OK;
     };
+    if (per_page) {
+        if (!ctx->d_tickets.ptr) {
+            if ((st = reserve(ctx, ctx->d_tickets, pq2_cu_ticket_bytes()))) return st;
+            PQ2_HIP(ctx, hipMemsetAsync(ctx->d_tickets.ptr, 0, pq2_cu_ticket_bytes(), stream));
+        }
+        if ((st = stamped(true, stream, [&] {
+                 return pq2_launch_decode(d_pages, static_cast<uint32_t>(n_pages), ctx->d_resume.ptr, d_run_pos, d_status,
+                                          ctx->d_state.ptr, static_cast<uint32_t *>(ctx->d_tickets.ptr), max_bits,
+                                          stream);
+             })))
+            return st;
+        rounds = 0;
+    }
     for (uint32_t r = 0; r < rounds; ++r) {
         if ((st = stamped(false, ps, [&] {
                  return pq2_launch_parse(d_pages, static_cast<uint32_t>(n_pages), ctx->d_resume.ptr, d_tile_page,
@@ -339,6 +363,10 @@ int32_t pq2_ctx_create(int32_t device_id, pq2_ctx **out) {
         const long long t = std::atoll(v);
         if (t > 0) ctx->min_rounded_tiles = static_cast<uint64_t>(t);
     }
+    if (const char *v = std::getenv("PQ2_MODE")) {
+        if (std::strcmp(v, "page") == 0) ctx->mode = pq2_ctx::kPerPage;
+        if (std::strcmp(v, "tile") == 0) ctx->mode = pq2_ctx::kPerTile;
+    }
     if (const char *v = std::getenv("PQ2_ROUND_SPLIT")) {
         double a = 0, b = 0, c = 0;
         if (std::sscanf(v, "%lf,%lf,%lf", &a, &b, &c) == 3 && 0 <= a && a <= b && b <= c && c <= 1)
@@ -357,7 +385,7 @@ int32_t pq2_ctx_destroy(pq2_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     for (DevBuf *b : {&ctx->d_meta, &ctx->d_status, &ctx->d_resume, &ctx->d_tile_page, &ctx->d_run_pos, &ctx->d_state,
-                      &ctx->d_in, &ctx->d_out})
+                      &ctx->d_tickets, &ctx->d_in, &ctx->d_out})
         if (b->ptr) (void)hipFree(b->ptr);
     for (hipStream_t s : {ctx->parse_stream, ctx->expand_stream[0], ctx->expand_stream[1]})
         if (s) (void)hipStreamDestroy(s);
@@ -564,6 +592,9 @@ int32_t pq2_decode_batch_host(pq2_ctx *ctx, const void *h_in, uint64_t in_bytes,
         if (lane) continue;
         if ((st = pq2_ctx_create(ctx->device, &lane))) return fail(ctx, st, "cannot create a lane of the host path");
         lane->profiling = false;
+        lane->mode = ctx->mode;
+        lane->min_rounded_tiles = ctx->min_rounded_tiles;
+        std::copy(ctx->round_split, ctx->round_split + kRounds - 1, lane->round_split);
         PQ2_HIP(ctx, hipStreamCreateWithFlags(&lane->lane_stream, hipStreamNonBlocking));
     }
     if (status && ctx->h_status_cap < n_pages) {

@@ -354,6 +354,20 @@ __device__ __forceinline__ uint32_t wave_inclusive_max(uint32_t v) {
     return v;
 }
 
+// Orders the LDS operations of one wave as the program has them (they execute in order; this keeps the
+// compiler from moving them) where a region of LDS is private to the wave.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// A load that sees what another wave of the same GPU has stored (and made visible with a release) although this
+// compute unit's vector cache may hold an older copy of the line.
+__device__ __forceinline__ uint32_t load_coherent(const uint32_t *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ---- stores -------------------------------------------------------------------
 
 __device__ __forceinline__ void store4(u32x4 v, out_u32 *p) {

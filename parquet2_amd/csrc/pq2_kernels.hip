@@ -110,22 +110,23 @@ asm volatile( \
 
 constexpr uint32_t kExplicit = 0x8080u;  // `lo` of a parked record that carries (kind, count, info) itself
 
+// The header walk of one page by one wave.  `win` (kWin bytes of LDS, private to the wave) holds stream byte a at
+// win[a - win_lo] for a in [win_lo, win_lo + kWin).  `publish(v)` is called, by all lanes, with the number of
+// values the listed runs cover once the entries that describe them (header positions, Resume) have been stored,
+// and with kAllParsed when the page's entries are complete; whoever consumes the entries while the walk is
+// still going waits on that number.
 // kWide: some page of the batch is wider than 16 bits.
-template <bool kWide>
-__global__ __launch_bounds__(64) void parse_kernel(const PageDev *__restrict__ pages, uint32_t n_pages,
-                                                   Resume *__restrict__ resume, uint32_t *__restrict__ tile_page,
-                                                   uint32_t *__restrict__ run_pos, int32_t *__restrict__ status,
-                                                   ParseState *__restrict__ state, uint32_t round) {
-    // win[a - win_lo] holds stream byte a for a in [win_lo, win_lo + kWin)
-    __shared__ __attribute__((aligned(16))) uint8_t win[kWin];
-
-    const uint32_t lane = threadIdx.x;
-    const uint32_t page = blockIdx.x;
-    if (page >= n_pages) return;
-    const PageDev pg = pages[page];
+constexpr uint32_t kAllParsed = 0xffffffffu;
+template <bool kWide, typename Publish>
+__device__ __forceinline__ void parse_page(const PageDev &pg, const uint32_t page, uint8_t *win,
+                                           Resume *__restrict__ resume, uint32_t *__restrict__ tile_page,
+                                           uint32_t *__restrict__ run_pos, int32_t *__restrict__ status,
+                                           ParseState *__restrict__ state, const uint32_t round,
+                                           const uint32_t lane, Publish publish) {
     const uint32_t n = pg.num_values;
     if (n == 0) {
         if (lane == 0 && round == 0) status[page] = 0;
+        publish(kAllParsed);
         return;
     }
     const uint32_t w = pg.num_bits;
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(64) void parse_kernel(const PageDev *__restrict__ p
         return resume + (size_t)pg.tile_number(b / kBlocksPerTile) * kBlocksPerTile + (b % kBlocksPerTile);
     };
     // expand_kernel finds its page through tile_page[tile]
-    if (round == 0)
+    if (round == 0 && tile_page != nullptr)
         for (uint32_t t = lane; t < (n_blocks + kBlocksPerTile - 1) / kBlocksPerTile; t += 64)
             tile_page[pg.tile_number(t)] = page;
 
@@ -149,7 +150,10 @@ __global__ __launch_bounds__(64) void parse_kernel(const PageDev *__restrict__ p
         ps.produced = __builtin_amdgcn_readfirstlane(ps.produced);
         ps.n_runs = __builtin_amdgcn_readfirstlane(ps.n_runs);
         ps.done = __builtin_amdgcn_readfirstlane(ps.done);
-        if (ps.done) return;
+        if (ps.done) {
+            publish(kAllParsed);
+            return;
+        }
     }
     // this round ends once the values of the page's tiles up to the round's last one are covered
     const uint64_t round_end = round + 1u < kRounds ? (uint64_t)pg.round_first(round + 1u) * kTileValues : n;
@@ -175,6 +179,7 @@ __global__ __launch_bounds__(64) void parse_kernel(const PageDev *__restrict__ p
             status[page] = st;
             state[page].done = 1u;
         }
+        publish(kAllParsed);
     };
 
     if (w == 0 || pg.in_len == 0 || w > 32) {  // decoder.rs:31-37: nothing to iterate
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(64) void parse_kernel(const PageDev *__restrict__ p
     };
     // moves the window so that [at, at + 32) is resident; at >= win_lo + kHalf
     auto slide = [&](uint32_t at) {
-        __syncthreads();  // every earlier window read of the wave is done before the window is overwritten
+        wave_sync();  // the window belongs to this wave alone, and its LDS operations execute in order
         if (at - win_lo + 32u <= kWin + kHalf) {
             // by one half: the upper half moves down, the prefetched half becomes the upper one
             u32x4 up[kHalfPieces];
@@ -222,7 +227,7 @@ __global__ __launch_bounds__(64) void parse_kernel(const PageDev *__restrict__ p
             store_half(kHalf, b);
         }
         load_half(win_lo + kWin, pre);  // lands while the chase works through the window
-        __syncthreads();
+        wave_sync();
     };
     auto resident = [&](uint32_t at, uint32_t bytes) { return at - win_lo + bytes <= kWin; };  // at >= win_lo
     auto rd = [&](uint32_t a) -> uint32_t {
@@ -236,7 +241,7 @@ __global__ __launch_bounds__(64) void parse_kernel(const PageDev *__restrict__ p
         load_half(win_lo + kWin, pre);
         store_half(0, a);
         store_half(kHalf, b);
-        __syncthreads();
+        wave_sync();
     }
 
     uint32_t pos = ps.pos;  // a-offset of the next header
@@ -360,12 +365,26 @@ __global__ __launch_bounds__(64) void parse_kernel(const PageDev *__restrict__ p
             return;
         }
         if (produced >= target) break;
+        publish(produced);
     }
     if (lane == 0) {
         ParseState out;
         out.pos = pos, out.produced = produced, out.n_runs = n_runs, out.done = 0;
         state[page] = out;
     }
+    publish(produced);
+}
+
+template <bool kWide>
+__global__ __launch_bounds__(64) void parse_kernel(const PageDev *__restrict__ pages, uint32_t n_pages,
+                                                   Resume *__restrict__ resume, uint32_t *__restrict__ tile_page,
+                                                   uint32_t *__restrict__ run_pos, int32_t *__restrict__ status,
+                                                   ParseState *__restrict__ state, uint32_t round) {
+    __shared__ __attribute__((aligned(16))) uint8_t win[kWin];
+    const uint32_t page = blockIdx.x;
+    if (page >= n_pages) return;
+    const PageDev pg = pages[page];
+    parse_page<kWide>(pg, page, win, resume, tile_page, run_pos, status, state, round, threadIdx.x, [](uint32_t) {});
 }
 
 // ---------------------------------------------------------------------------
@@ -408,7 +427,9 @@ constexpr uint32_t kChunkSlots = kSpanChunks + 8u;     // ... + 2 when the outpu
 //            the first position of a run are left to one last step in which
 //            lane r works through the chunk that run r + 1 starts in, value
 //            by value.
-template <int W>
+// kCoh: the header list is still being written by another wave (see decode_kernel): its entries are loaded past
+// this compute unit's vector cache.
+template <int W, bool kCoh>
 __device__ __forceinline__ void expand_block(const __amdgpu_buffer_rsrc_t rsrc, Window &win, uint2 *tbl,
                                              uint32_t *cidx, const Resume rs, const uint32_t hp_first,
                                              const uint32_t *__restrict__ hdrs, const uint32_t end, const uint32_t n,
@@ -475,7 +496,7 @@ __device__ __forceinline__ void expand_block(const __amdgpu_buffer_rsrc_t rsrc, 
                 if (first_pass)
                     hp = hp_first;
                 else if (lane < kLaneRuns)
-                    hp = hdrs[ridx + 1u + lane];
+                    hp = kCoh ? load_coherent(&hdrs[ridx + 1u + lane]) : hdrs[ridx + 1u + lane];
                 const uint32_t hp0 = __builtin_amdgcn_readfirstlane(hp);
                 if (hp0 != kEndPos && !win.holds(hp0 & ~3u, (hp0 & ~3u) + 24u)) {
                     if (kind == kRle) win.fill(rsrc, hp0, est, lane);  // nothing of this pass lives in the window yet
@@ -610,7 +631,7 @@ __device__ __forceinline__ void expand_block(const __amdgpu_buffer_rsrc_t rsrc, 
             // ---- next pass (rare: more than 63 runs in the block, or bytes beyond the window) --------------
             if (hi < block_n && !alone) {  // run ridx + 1 + g becomes the first run
                 ridx += 1u + g;
-                const uint32_t at = __builtin_amdgcn_readfirstlane(hdrs[ridx]);
+                const uint32_t at = __builtin_amdgcn_readfirstlane(kCoh ? load_coherent(&hdrs[ridx]) : hdrs[ridx]);
                 if (!win.holds(at & ~3u, (at & ~3u) + 24u)) win.fill(rsrc, at, (((block_n - hi) * w) >> 3) + 64u, lane);
                 auto rd = [&](uint32_t a) -> uint32_t { return __builtin_amdgcn_readfirstlane(win.dword(a)); };
                 const RunInfo run = decode_run(rd, at, end, w, n - (block_start + hi));
@@ -640,7 +661,7 @@ __device__ __forceinline__ void expand_block(const __amdgpu_buffer_rsrc_t rsrc, 
 // cannot be waited for without waiting for the store as well; this way no
 // block waits for the stores of the one before it.  `rs4`: lane j holds the
 // Resume entry of the tile's block j.
-template <int W>
+template <int W, bool kCoh>
 __device__ __forceinline__ void expand_tile(const __amdgpu_buffer_rsrc_t rsrc, Window &win, uint2 *tbl,
                                             uint32_t *cidx, const u32x4 rs4, const uint32_t *__restrict__ hdrs,
                                             const uint32_t end, const uint32_t n, const uint32_t tile_first,
@@ -675,7 +696,10 @@ __device__ __forceinline__ void expand_tile(const __amdgpu_buffer_rsrc_t rsrc, W
     for (uint32_t i = 0; i < kSpans; ++i) {
         hp[i] = kEndPos;
         const bool wanted = i < spans && !__builtin_amdgcn_readlane((uint32_t)alone, i * kSpanBlocks);
-        if (wanted && lane < 63u) hp[i] = hdrs[__builtin_amdgcn_readlane(rs4.x, i * kSpanBlocks) + 1u + lane];
+        if (wanted && lane < 63u) {
+            const uint32_t *at = &hdrs[__builtin_amdgcn_readlane(rs4.x, i * kSpanBlocks) + 1u + lane];
+            hp[i] = kCoh ? load_coherent(at) : *at;
+        }
     }
     // the spans lie one behind the other in the stream: the first one that needs bytes needs the earliest
     uint32_t tile_from = kEndPos, first_needing = 0;
@@ -692,8 +716,56 @@ __device__ __forceinline__ void expand_tile(const __amdgpu_buffer_rsrc_t rsrc, W
         uint32_t hpi = hp[0];
 #pragma unroll
         for (uint32_t k = 1; k < kSpans; ++k) hpi = i == k ? hp[k] : hpi;
-        expand_block<W>(rsrc, win, tbl, cidx, resume_of(i), hpi, hdrs, end, n, tile_first + i * kSpanValues,
+        expand_block<W, kCoh>(rsrc, win, tbl, cidx, resume_of(i), hpi, hdrs, end, n, tile_first + i * kSpanValues,
                         length_of(i), out + i * kSpanValues, lane);
+    }
+}
+
+// One wave decodes tile `tile_first / kTileValues` of page `pg` (`rs4`: lane j holds the Resume entry of the
+// tile's block j) with `win_lds` / `tbl` / `cidx` as its private LDS.
+template <bool kCoh>
+__device__ __forceinline__ void expand_page_tile(const PageDev &pg, const u32x4 rs4, const uint32_t tile_first,
+                                                 const uint32_t *__restrict__ run_pos, uint8_t *win_lds,
+                                                 const uint32_t win_bytes, const uint32_t win_bit_mask, uint2 *tbl,
+                                                 uint32_t *cidx, const uint32_t lane) {
+    const uint32_t n = pg.num_values;
+    const uint32_t delta = (uint32_t)(pg.in_addr & 15u);
+    const uint32_t end = delta + pg.in_len;
+    const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(pg.in_addr - delta, (end + 3u) & ~3u);
+
+    Window win;
+    win.lo = win.hi = 0;
+    win.lds = win_lds;
+    win.cap = win_bytes;
+    win.bit_mask = win_bit_mask;
+    if (lane < 2) tbl[kTableRuns + lane] = make_uint2(kNoRun, 0u);  // read by tbl[j + 1] only
+    out_u32 *const out = (out_u32 *)pg.out_addr + tile_first;
+
+    switch (pg.num_bits) {
+#define PQ2_W(N)                                                                                               \
+    case N:                                                                                                    \
+        expand_tile<N, kCoh>(rsrc, win, tbl, cidx, rs4, run_pos + pg.run_base, end, n, tile_first, out, lane); \
+        break;
+#ifdef PQ2_ONLY_W  // single-width build for reading the generated code
+        PQ2_W(PQ2_ONLY_W)
+#else
+        PQ2_W(1) PQ2_W(2) PQ2_W(3) PQ2_W(4) PQ2_W(5) PQ2_W(6) PQ2_W(7) PQ2_W(8)
+        PQ2_W(9) PQ2_W(10) PQ2_W(11) PQ2_W(12) PQ2_W(13) PQ2_W(14) PQ2_W(15) PQ2_W(16)
+        PQ2_W(17) PQ2_W(18) PQ2_W(19) PQ2_W(20) PQ2_W(21) PQ2_W(22) PQ2_W(23) PQ2_W(24)
+        PQ2_W(25) PQ2_W(26) PQ2_W(27) PQ2_W(28) PQ2_W(29) PQ2_W(30) PQ2_W(31) PQ2_W(32)
+#endif
+#undef PQ2_W
+        default: {  // width 0: zeros
+            const uint32_t count = min(kTileValues, n - tile_first);
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            const uint32_t head = min((4u - (uint32_t)(((uintptr_t)out >> 2) & 3u)) & 3u, count);
+            if (lane < head) out[lane] = 0u;
+            const uint32_t groups = (count - head) >> 2;
+            for (uint32_t g = lane; g < groups; g += 64u) store4(z, out + head + 4u * g);
+            const uint32_t tail = head + 4u * groups;
+            if (lane < count - tail) out[tail + lane] = 0u;
+            break;
+        }
     }
 }
 
@@ -718,49 +790,103 @@ __global__ __launch_bounds__(256, PQ2_EXPAND_WAVES) void expand_kernel(const Pag
     u32x4 rs4 = {0u, 0u, 0u, 0u};
     if (lane < kBlocksPerTile) rs4 = ((const u32x4 *)resume)[(size_t)tile * kBlocksPerTile + lane];
     const PageDev pg = pages[tile_page[tile]];
-    const uint32_t n = pg.num_values;
     const uint32_t tile_first = (pg.round_first(round) + (tile - pg.round_base(round))) * kTileValues;
-    if (tile_first >= n) return;
+    if (tile_first >= pg.num_values) return;
 
-    const uint32_t delta = (uint32_t)(pg.in_addr & 15u);
-    const uint32_t end = delta + pg.in_len;
-    const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(pg.in_addr - delta, (end + 3u) & ~3u);
-
-    Window win;
-    win.lo = win.hi = 0;
-    win.lds = lds + wave * win_bytes;
-    win.cap = win_bytes;
-    win.bit_mask = win_bit_mask;
     uint2 *tbl = (uint2 *)(lds + 4u * win_bytes + 32u) + wave * (kTableRuns + 2);
     uint32_t *cidx = (uint32_t *)(lds + 4u * win_bytes + 32u + 4u * (kTableRuns + 2) * 8u) + wave * kChunkSlots;
-    if (lane < 2) tbl[kTableRuns + lane] = make_uint2(kNoRun, 0u);  // read by tbl[j + 1] only
-    out_u32 *const out = (out_u32 *)pg.out_addr + tile_first;
+    expand_page_tile<false>(pg, rs4, tile_first, run_pos, lds + wave * win_bytes, win_bytes, win_bit_mask, tbl, cidx,
+                            lane);
+}
 
-    switch (pg.num_bits) {
-#define PQ2_W(N)                                                                                    \
-    case N:                                                                                         \
-        expand_tile<N>(rsrc, win, tbl, cidx, rs4, run_pos + pg.run_base, end, n, tile_first, out, lane); \
-        break;
-#ifdef PQ2_ONLY_W  // single-width build for reading the generated code
-        PQ2_W(PQ2_ONLY_W)
-#else
-        PQ2_W(1) PQ2_W(2) PQ2_W(3) PQ2_W(4) PQ2_W(5) PQ2_W(6) PQ2_W(7) PQ2_W(8)
-        PQ2_W(9) PQ2_W(10) PQ2_W(11) PQ2_W(12) PQ2_W(13) PQ2_W(14) PQ2_W(15) PQ2_W(16)
-        PQ2_W(17) PQ2_W(18) PQ2_W(19) PQ2_W(20) PQ2_W(21) PQ2_W(22) PQ2_W(23) PQ2_W(24)
-        PQ2_W(25) PQ2_W(26) PQ2_W(27) PQ2_W(28) PQ2_W(29) PQ2_W(30) PQ2_W(31) PQ2_W(32)
-#endif
-#undef PQ2_W
-        default: {  // width 0: zeros
-            const uint32_t count = min(kTileValues, n - tile_first);
-            const u32x4 z = {0u, 0u, 0u, 0u};
-            const uint32_t head = min((4u - (uint32_t)(((uintptr_t)out >> 2) & 3u)) & 3u, count);
-            if (lane < head) out[lane] = 0u;
-            const uint32_t groups = (count - head) >> 2;
-            for (uint32_t g = lane; g < groups; g += 64u) store4(z, out + head + 4u * g);
-            const uint32_t tail = head + 4u * groups;
-            if (lane < count - tail) out[tail + lane] = 0u;
-            break;
+// ---------------------------------------------------------------------------
+// decode_kernel: both steps in one workgroup per page
+//
+// Wave 0 walks the page's headers (parse_page) and publishes, in LDS, how many values the entries it has stored
+// cover; waves 1..3 take the page's tiles in turn (tile t goes to wave 1 + t % 3), wait until the walk has
+// passed the tile and expand it as expand_kernel does.  The walk is a chain of dependent steps that leaves the
+// machine idle, and the expansion is memory traffic: running them side by side hides the first behind the
+// second, and the stream bytes the expanding waves read were loaded by the walk a moment ago, so they come out
+// of the cache and the stream crosses the memory bus once.  The waves of a workgroup are resident together, so
+// the walk always advances and every wait ends: the walk publishes kAllParsed on every way out.
+//
+// Dynamic LDS: the walk's window (kWin), three stream windows of `win_bytes`, 32 spare bytes, three run
+// tables, three chunk indexes, the progress word.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kDecodeExpanders = 3;
+constexpr uint32_t kMaxPolls = 1u << 24;  // of about 0.1 us each: far beyond the longest header walk of a page
+constexpr uint32_t kCuTickets = 4096;     // entries of the per-compute-unit ticket table (see decode_kernel)
+// Which wave of the workgroup walks the headers.  The walk issues an instruction whenever its SIMD lets it, and
+// the workgroups that share a compute unit would all put wave 0 on the same SIMD, where the walks would take
+// turns; so every workgroup draws a ticket from its compute unit's counter and gives the walk to the wave that
+// sits on SIMD `ticket % 4`: four resident workgroups, four SIMDs.  (A wrong guess about the placement costs
+// speed, nothing else: any wave can take either role.)
+__device__ __forceinline__ uint32_t pick_walker(uint32_t *cu_tickets, uint32_t *scratch /* 8 words of LDS */,
+                                                const uint32_t wave, const uint32_t lane) {
+    const uint32_t hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_REG_HW_ID
+    const uint32_t xcc_id = __builtin_amdgcn_s_getreg((3 << 11) | 20);  // HW_REG_XCC_ID
+    if (lane == 0) scratch[wave] = (hw_id >> 4) & 3u;                   // SIMD_ID
+    if (threadIdx.x == 0)  // CU_ID, SH_ID, SE_ID of this compute unit | accelerator die
+        scratch[4] = atomicAdd(&cu_tickets[(((hw_id >> 8) & 0xffu) | (xcc_id << 8)) & (kCuTickets - 1u)], 1u);
+    __syncthreads();
+    const uint32_t target = scratch[4] & 3u;
+    uint32_t walker = 0;
+    for (uint32_t k = 4; k-- > 0;)
+        if (scratch[k] == target) walker = k;
+    return __builtin_amdgcn_readfirstlane(walker);
+}
+
+template <bool kWide>
+__global__ __launch_bounds__(256, 4) void decode_kernel(const PageDev *__restrict__ pages, uint32_t n_pages,
+                                                         Resume *__restrict__ resume, uint32_t *__restrict__ run_pos,
+                                                         int32_t *__restrict__ status, ParseState *__restrict__ state,
+                                                         uint32_t *__restrict__ cu_tickets, uint32_t win_bytes,
+                                                         uint32_t win_bit_mask) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t page = blockIdx.x;
+    if (page >= n_pages) return;
+    const PageDev pg = pages[page];
+    uint8_t *const tables = lds + kWin + kDecodeExpanders * win_bytes + 32u;
+    uint32_t *const parsed = (uint32_t *)(tables + kDecodeExpanders * ((kTableRuns + 2) * 8u + kChunkSlots * 4u));
+    if (threadIdx.x == 0) *parsed = 0u;
+    const uint32_t walker = pick_walker(cu_tickets, parsed + 4, wave, lane);  // with a workgroup barrier inside
+
+    if (wave == walker) {
+        parse_page<kWide>(pg, page, lds, resume, nullptr, run_pos, status, state, 0u, lane, [&](uint32_t covered) {
+            // release: the entries stored before are visible to whoever sees the new number
+            if (lane == 0) __hip_atomic_store(parsed, covered, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        });
+        return;
+    }
+    const uint32_t e = wave - (wave > walker ? 1u : 0u);
+    uint2 *tbl = (uint2 *)tables + e * (kTableRuns + 2);
+    uint32_t *cidx = (uint32_t *)(tables + kDecodeExpanders * (kTableRuns + 2) * 8u) + e * kChunkSlots;
+    const uint32_t n = pg.num_values;
+    const uint32_t n_tiles = (n + kTileValues - 1u) / kTileValues;
+    for (uint32_t t = e; t < n_tiles; t += kDecodeExpanders) {
+        const uint32_t need = min((t + 1u) * kTileValues, n);
+        uint32_t polls = 0;
+        while (__hip_atomic_load(parsed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++polls == kMaxPolls) {  // never seen; a wait that cannot end would hang the GPU
+                if (lane == 0) status[page] = 6;  // PQ2_DEVICE_ERROR
+                return;
+            }
         }
+        // the tile's four Resume entries, one per lane, past the vector cache (the walk wrote them just now)
+        const uint32_t *rs = (const uint32_t *)(resume + (size_t)(pg.round_base(0) + t) * kBlocksPerTile);
+        u32x4 rs4 = {0u, 0u, 0u, 0u};
+        if (lane < kBlocksPerTile) {
+            rs4.x = load_coherent(rs + 4u * lane);
+            rs4.y = load_coherent(rs + 4u * lane + 1u);
+            rs4.z = load_coherent(rs + 4u * lane + 2u);
+            rs4.w = load_coherent(rs + 4u * lane + 3u);
+        }
+        expand_page_tile<true>(pg, rs4, t * kTileValues, run_pos, lds + kWin + e * win_bytes, win_bytes, win_bit_mask,
+                               tbl, cidx, lane);
     }
 }
 
@@ -818,6 +944,36 @@ extern "C" hipError_t pq2_launch_expand(const void *pages, const uint32_t *tile_
     hipLaunchKernelGGL(pq2::expand_kernel, dim3((n_tiles + 3u) / 4u), dim3(256), lds_bytes, stream,
                        (const pq2::PageDev *)pages, tile_page, (const pq2::Resume *)resume, run_pos, tile_start,
                        tile_start + n_tiles, round, win_bytes, pow2 * 8u - 1u);
+    return hipGetLastError();
+}
+
+// One workgroup per page; `max_bits` as for pq2_launch_expand.
+extern "C" uint32_t pq2_cu_ticket_bytes() { return pq2::kCuTickets * 4u; }
+
+extern "C" hipError_t pq2_launch_decode(const void *pages, uint32_t n_pages, void *resume, uint32_t *run_pos,
+                                        int32_t *status, void *state, uint32_t *cu_tickets, uint32_t max_bits,
+                                        hipStream_t stream) {
+    if (n_pages == 0) return hipSuccess;
+    constexpr uint32_t kFixed = pq2::kWin + 32u +
+                                pq2::kDecodeExpanders * ((pq2::kTableRuns + 2u) * 8u + pq2::kChunkSlots * 4u) + 64u;
+    uint32_t win_bytes = (pq2::kTileValues / 8u) * (max_bits ? max_bits : 1u) + 256u;
+    if (win_bytes < 2048u) win_bytes = 2048u;
+    if (win_bytes > 16384u) win_bytes = 16384u;  // the widest pages refill their window inside a tile
+    win_bytes &= ~15u;
+    uint32_t pow2 = 2048u;
+    while (pow2 < win_bytes) pow2 <<= 1;
+    // positions masked with `pow2 * 8 - 1` behind the last window's base stay inside the allocation
+    uint32_t lds_bytes = kFixed + pq2::kDecodeExpanders * win_bytes;
+    const uint32_t reach = pq2::kWin + (pq2::kDecodeExpanders - 1u) * win_bytes + pow2 + 64u;
+    if (lds_bytes < reach) lds_bytes = reach;
+    if (max_bits > 16u)
+        hipLaunchKernelGGL(pq2::decode_kernel<true>, dim3(n_pages), dim3(256), lds_bytes, stream,
+                           (const pq2::PageDev *)pages, n_pages, (pq2::Resume *)resume, run_pos, status,
+                           (pq2::ParseState *)state, cu_tickets, win_bytes, pow2 * 8u - 1u);
+    else
+        hipLaunchKernelGGL(pq2::decode_kernel<false>, dim3(n_pages), dim3(256), lds_bytes, stream,
+                           (const pq2::PageDev *)pages, n_pages, (pq2::Resume *)resume, run_pos, status,
+                           (pq2::ParseState *)state, cu_tickets, win_bytes, pow2 * 8u - 1u);
     return hipGetLastError();
 }
 

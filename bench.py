@@ -5,7 +5,8 @@
 
 One step = one pass of the decoder (pq2_decode_batch_device: parse + expand kernels) over one batch of
 synthetic RLE_DICTIONARY index pages already resident in HBM: `--pages` pages per GPU of 2^20 values, bit
-width 12, mixed RLE / bit-packed runs (BASELINE.json configs[1]).  With N > 1 the script runs under
+width 12, mixed RLE / bit-packed runs (BASELINE.json configs[1]; the default of 2048 pages per GPU is the per-GPU
+share of configs[4]).  With N > 1 the script runs under
 torch.distributed.run, one rank per GPU; every rank decodes its own shard of the global page list
 (pq2_partition_pages), there is no data-path collective, and the reported value is the whole-job rate
 (all ranks' output bytes / slowest rank's time).  Rank 0 prints one JSON line.
@@ -35,7 +36,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pages", type=int, default=1024, help="pages per GPU in one batch")
+    ap.add_argument("--pages", type=int, default=2048, help="pages per GPU in one batch")
     ap.add_argument("--values", type=int, default=1 << 20, help="values per page")
     ap.add_argument("--bits", type=int, default=12)
     ap.add_argument("--distinct", type=int, default=16, help="distinct generated pages (replicated on the device)")

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -84,6 +85,8 @@ struct pq2_ctx {
     // parse_kernel + expand_kernel, one wave per 4096 values, in rounds (few, large pages).  PQ2_MODE=page|tile
     // forces one of them.
     enum Mode { kAuto, kPerPage, kPerTile } mode = kAuto;
+    bool one_expand_stream = true;  // the expand launches of a batch follow each other (PQ2_EXPAND_STREAMS=2: they take turns on two streams)
+    bool split_given = false;       // PQ2_ROUND_SPLIT was set
     // rounds: parse_kernel of round r + 1 runs on parse_stream while expand_kernel of round r runs on expand_stream
     // (two of them, taken in turn: the expand launches of one batch do not depend on each other, so the next one
     // starts while the last waves of the previous one drain)
@@ -219,13 +222,21 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
                            total_values <= n_pages * kFusedMaxPageValues);
     // tiles are numbered round-major: all tiles of round 0 of all pages, then round 1, ...
     const bool split = !per_page && tiles >= ctx->min_rounded_tiles;
+    // Nothing hides the parse of the first part, and the walk of a page takes the same time whatever the batch
+    // holds while the expansion grows with it: the larger the batch, the smaller the first part.
+    double round_split[kRounds - 1];
+    std::copy(ctx->round_split, ctx->round_split + kRounds - 1, round_split);
+    if (!ctx->split_given && tiles > (1ull << 30) / kTileValues) {
+        const double f = 0.25 * std::sqrt(double((1ull << 30) / kTileValues) / double(tiles));
+        round_split[0] = f < 0.08 ? 0.08 : f;
+    }
     uint64_t round_start[kRounds + 1] = {0};
     for (uint64_t i = 0; i < n_pages; ++i) {
         PageDev &p = pages[i];
         const uint64_t t = (uint64_t(p.num_values) + kTileValues - 1) / kTileValues;
         p.round_tile[0] = 0;
         for (uint32_t r = 1; r < kRounds; ++r) {
-            const uint64_t first = split ? static_cast<uint64_t>(ctx->round_split[r - 1] * double(t) + 0.5) : t;
+            const uint64_t first = split ? static_cast<uint64_t>(round_split[r - 1] * double(t) + 0.5) : t;
             p.round_tile[r] = static_cast<uint32_t>(std::min(t, std::max<uint64_t>(first, p.round_tile[r - 1])));
         }
         for (uint32_t r = 0; r < kRounds; ++r)
@@ -279,7 +290,7 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
         }
         ps = ctx->parse_stream;
         es[0] = ctx->expand_stream[0];
-        es[1] = ctx->expand_stream[1];
+        es[1] = ctx->expand_stream[ctx->one_expand_stream ? 0 : 1];
         PQ2_HIP(ctx, hipEventRecord(ctx->fork, stream));
         PQ2_HIP(ctx, hipStreamWaitEvent(ps, ctx->fork, 0));
         PQ2_HIP(ctx, hipStreamWaitEvent(es[0], ctx->fork, 0));
@@ -370,6 +381,7 @@ int32_t pq2_ctx_create(int32_t device_id, pq2_ctx **out) {
         const long long t = std::atoll(v);
         if (t > 0) ctx->min_rounded_tiles = static_cast<uint64_t>(t);
     }
+    if (const char *v = std::getenv("PQ2_EXPAND_STREAMS")) ctx->one_expand_stream = std::atoi(v) != 2;
     if (const char *v = std::getenv("PQ2_MODE")) {
         if (std::strcmp(v, "page") == 0) ctx->mode = pq2_ctx::kPerPage;
         if (std::strcmp(v, "tile") == 0) ctx->mode = pq2_ctx::kPerTile;
@@ -377,7 +389,7 @@ int32_t pq2_ctx_create(int32_t device_id, pq2_ctx **out) {
     if (const char *v = std::getenv("PQ2_ROUND_SPLIT")) {
         double a = 0, b = 0, c = 0;
         if (std::sscanf(v, "%lf,%lf,%lf", &a, &b, &c) == 3 && 0 <= a && a <= b && b <= c && c <= 1)
-            ctx->round_split[0] = a, ctx->round_split[1] = b, ctx->round_split[2] = c;
+            ctx->round_split[0] = a, ctx->round_split[1] = b, ctx->round_split[2] = c, ctx->split_given = true;
     }
     if (hipEventCreateWithFlags(&ctx->meta_copied, hipEventDisableTiming) != hipSuccess) {
         delete ctx;

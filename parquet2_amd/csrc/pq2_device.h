@@ -427,6 +427,50 @@ __device__ __forceinline__ uint32_t field_at(const uint8_t *lds, uint32_t bit) {
     return x & mask;
 }
 
+// Keeps a value in a register at this point of the program: a load that produces it has been issued, and is
+// waited for, here and not inside a later branch.
+__device__ __forceinline__ void pin(uint32_t &x) { asm volatile("" : "+v"(x)); }
+
+// The dwords that hold four consecutive W-bit fields starting at LDS bit position `bit`, read now, extracted later
+// (fields4_at in two halves, so that the reads of several chunks can be in flight together).
+template <int W>
+struct FieldWords {
+    static constexpr int NY = (4 * W + 31) / 32;
+    uint32_t x[NY + 1];
+    uint32_t s;
+    __device__ __forceinline__ void pin_all() {
+#pragma unroll
+        for (int i = 0; i <= NY; ++i) pin(x[i]);
+    }
+    __device__ __forceinline__ u32x4 fields4() const {
+        uint32_t y[NY];
+#pragma unroll
+        for (int i = 0; i < NY; ++i) y[i] = __builtin_amdgcn_alignbit(x[i + 1], x[i], s);
+        constexpr uint32_t mask = W == 32 ? 0xffffffffu : ((1u << (W & 31)) - 1u);
+        uint32_t o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int lo = (i * W) >> 5;
+            const int shf = (i * W) & 31;
+            if (shf + W <= 32)
+                o[i] = W == 32 ? y[lo] : ((y[lo] >> shf) & mask);
+            else
+                o[i] = __builtin_amdgcn_alignbit(y[lo + 1 < NY ? lo + 1 : lo], y[lo], shf) & mask;
+        }
+        const u32x4 res = {o[0], o[1], o[2], o[3]};
+        return res;
+    }
+};
+template <int W>
+__device__ __forceinline__ FieldWords<W> load_fields(const uint8_t *lds, uint32_t bit) {
+    FieldWords<W> f;
+    const uint32_t *src = (const uint32_t *)(lds + ((bit >> 3) & ~3u));
+#pragma unroll
+    for (int i = 0; i <= FieldWords<W>::NY; ++i) f.x[i] = src[i];
+    f.s = bit & 31u;
+    return f;
+}
+
 // Four consecutive W-bit fields starting at LDS bit position `bit`: ceil(4W / 32) + 1 dword reads, one funnel
 // shift per dword to bring the first field to bit 0, then one extraction per field at a constant position.
 template <int W>

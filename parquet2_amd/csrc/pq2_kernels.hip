@@ -402,6 +402,10 @@ constexpr uint32_t kSpanBlocks = PQ2_SPAN_BLOCKS;  // 1, 2 or 4
 constexpr uint32_t kSpanValues = kSpanBlocks * kBlockValues;
 constexpr uint32_t kSpanChunks = kSpanValues / 4u;     // chunks of 4 values per span ...
 constexpr uint32_t kChunkSlots = kSpanChunks + 8u;     // ... + 2 when the output is not 16-byte aligned, rounded up
+#ifndef PQ2_STEP_GROUP
+#define PQ2_STEP_GROUP 5
+#endif
+constexpr uint32_t kStepGroup = PQ2_STEP_GROUP;  // emission steps whose LDS reads are in flight together
 
 // One wave decodes the span [block_start, block_start + block_n) of a page
 // whose width is W (block_n <= kSpanValues).  `tbl` (kTableRuns + 2 entries), `cidx` (kChunkSlots entries) and
@@ -563,30 +567,59 @@ __device__ __forceinline__ void expand_block(const __amdgpu_buffer_rsrc_t rsrc, 
 
             // ---- phase 2: one chunk per lane and step ---------------------------------------------------
             // The steps do not depend on each other and there are at most 4 * kSpanBlocks + 1 of them (one more
-            // than the chunks of a span when the output is not 16-byte aligned): they are written out, without
-            // branches up to the store, so that the LDS reads of several steps (chunk index -> table entry ->
-            // stream dwords) are in flight together.
+            // than the chunks of a span when the output is not 16-byte aligned).  Every step is a chain of three
+            // dependent LDS reads (chunk index -> table entry -> stream dwords); the steps are taken in groups
+            // whose reads of one kind are issued together and waited for once (`pin` keeps the compiler from
+            // sinking a read into the branch that uses it, which would serialise the chains).
             const uint32_t q_end = (hi + mis + 3u) >> 2;
             const uint32_t q_first = ((lo + mis) >> 2) + lane;
             bool ragged = false;  // some lane holds the first or last chunk of the span, and not all of it
+            constexpr uint32_t kSteps = 4u * kSpanBlocks + 1u;
 #pragma unroll
-            for (uint32_t step = 0; step < 4u * kSpanBlocks + 1u; ++step) {
-                const uint32_t q = q_first + 64u * step;
-                const bool active = q < q_end;
-                const int32_t p = (int32_t)(q * 4u) - (int32_t)mis;
-                const uint32_t j = cidx[min(q, kChunkSlots - 1u)];
-                // this entry and the key of the next one (two naturally aligned reads: a 16-byte read at an
+            for (uint32_t g0 = 0; g0 < kSteps; g0 += kStepGroup) {
+                uint32_t j[kStepGroup];
+#pragma unroll
+                for (uint32_t i = 0; i < kStepGroup; ++i)
+                    if (g0 + i < kSteps) j[i] = cidx[min(q_first + 64u * (g0 + i), kChunkSlots - 1u)];
+#pragma unroll
+                for (uint32_t i = 0; i < kStepGroup; ++i)
+                    if (g0 + i < kSteps) pin(j[i]);
+                // the entry and the key of the next one (two naturally aligned reads: a 16-byte read at an
                 // 8-byte boundary would be replayed)
-                const uint2 e = tbl[j];
-                const uint32_t nxt = tbl[j + 1u].x;
-                // no run starts behind the chunk's first position
-                const bool single = active && ((((uint32_t)(p + 3)) << 1) | 1u) < nxt;
-                const bool full = p >= (int32_t)lo && p + 4 <= (int32_t)hi;
-                const u32x4 f = fields4_at<W>(win.lds, (e.y + (uint32_t)p * w) & bit_mask);
-                const bool rle = (e.x & 1u) != 0u;
-                const u32x4 v = {rle ? e.y : f.x, rle ? e.y : f.y, rle ? e.y : f.z, rle ? e.y : f.w};
-                if (single && full) store4(v, out + p);
-                ragged = ragged || (single && !full);
+                uint2 e[kStepGroup];
+                uint32_t nxt[kStepGroup];
+#pragma unroll
+                for (uint32_t i = 0; i < kStepGroup; ++i)
+                    if (g0 + i < kSteps) e[i] = tbl[j[i]], nxt[i] = tbl[j[i] + 1u].x;
+#pragma unroll
+                for (uint32_t i = 0; i < kStepGroup; ++i)
+                    if (g0 + i < kSteps) pin(e[i].x), pin(e[i].y), pin(nxt[i]);
+                FieldWords<W> x[kStepGroup];
+#pragma unroll
+                for (uint32_t i = 0; i < kStepGroup; ++i)
+                    if (g0 + i < kSteps) {
+                        const int32_t p = (int32_t)((q_first + 64u * (g0 + i)) * 4u) - (int32_t)mis;
+                        x[i] = load_fields<W>(win.lds, (e[i].y + (uint32_t)p * w) & bit_mask);
+                    }
+#pragma unroll
+                for (uint32_t i = 0; i < kStepGroup; ++i)
+                    if (g0 + i < kSteps) x[i].pin_all();
+#pragma unroll
+                for (uint32_t i = 0; i < kStepGroup; ++i)
+                    if (g0 + i < kSteps) {
+                        const uint32_t q = q_first + 64u * (g0 + i);
+                        const bool active = q < q_end;
+                        const int32_t p = (int32_t)(q * 4u) - (int32_t)mis;
+                        // no run starts behind the chunk's first position
+                        const bool single = active & (((((uint32_t)(p + 3)) << 1) | 1u) < nxt[i]);
+                        const bool full = (p >= (int32_t)lo) & (p + 4 <= (int32_t)hi);
+                        const u32x4 f = x[i].fields4();
+                        const bool rle = (e[i].x & 1u) != 0u;
+                        const uint32_t r = e[i].y;
+                        const u32x4 v = {rle ? r : f.x, rle ? r : f.y, rle ? r : f.z, rle ? r : f.w};
+                        if (single & full) store4(v, out + p);
+                        ragged = ragged | (single & !full);
+                    }
             }
             if (__builtin_expect(__ballot(ragged) != 0, 0)) {
                 // the first and the last chunk of the span, where they lie inside one run: position by position
@@ -605,28 +638,39 @@ __device__ __forceinline__ void expand_block(const __amdgpu_buffer_rsrc_t rsrc, 
                         out[pos] = (e.x & 1u) ? e.y : f;
                 }
             }
-            // the chunks in which a run starts: lane r takes the one of run r + 1, value by value
+            // the chunks in which a run starts: lane r takes the one of run r + 1, value by value.  The chunk's
+            // four positions lie in the run that holds its first position and the up to three behind it (runs in
+            // the table hold at least one value); their entries are read together, then the four fields.
             if (key != kNoRun) {
                 const uint32_t q = (start + mis) >> 2;
                 const int32_t p = (int32_t)(q * 4u) - (int32_t)mis;
-                uint32_t j = cidx[q];
-                uint2 cur = tbl[j];
-                uint32_t nxt = tbl[j + 1u].x;
-                uint32_t v[4];
+                const uint32_t j0 = cidx[q];
+                uint2 t[5];  // entries j0 .. j0 + 4 (behind the table's end: the sentinel)
+#pragma unroll
+                for (uint32_t i = 0; i < 5u; ++i) t[i] = tbl[min(j0 + i, kTableRuns + 1u)];
+#pragma unroll
+                for (uint32_t i = 0; i < 5u; ++i) pin(t[i].x), pin(t[i].y);
+                uint2 cur[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const uint32_t pk = (uint32_t)max(p + k, (int32_t)lo);
-                    if (((pk << 1) | 1u) >= nxt) {  // runs hold at least one value: one step forward is enough
-                        ++j;
-                        cur = tbl[j];
-                        nxt = tbl[j + 1u].x;
+                    if (((pk << 1) | 1u) >= t[1].x) {  // one step forward is enough: the window moves up
+#pragma unroll
+                        for (uint32_t i = 0; i < 4u; ++i) t[i] = t[i + 1u];
                     }
-                    const uint32_t f = field_at<W>(win.lds, (cur.y + pk * w) & bit_mask);
-                    v[k] = (cur.x & 1u) ? cur.y : f;
+                    cur[k] = t[0];
+                }
+                uint32_t f[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t pk = (uint32_t)max(p + k, (int32_t)lo);
+                    f[k] = field_at<W>(win.lds, (cur[k].y + pk * w) & bit_mask);
                 }
 #pragma unroll
+                for (int k = 0; k < 4; ++k) pin(f[k]);
+#pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    if (p + k >= (int32_t)lo && p + k < (int32_t)hi) out[p + k] = v[k];
+                    if (p + k >= (int32_t)lo && p + k < (int32_t)hi) out[p + k] = (cur[k].x & 1u) ? cur[k].y : f[k];
             }
             // ---- next pass (rare: more than 63 runs in the block, or bytes beyond the window) --------------
             if (hi < block_n && !alone) {  // run ridx + 1 + g becomes the first run

@@ -45,6 +45,9 @@ def parse_args():
     ap.add_argument("--host-path", action="store_true",
                     help="time pq2_decode_batch_host instead (page-locked host buffers in, host buffers out: the "
                          "copies over PCIe are inside the timed region); prints its own JSON line")
+    ap.add_argument("--gather-bytes", type=int, default=0, choices=[0, 4, 8, 12],
+                    help="time pq2_decode_dict_batch_device instead (indices -> dictionary values of this many bytes, "
+                         "a dictionary of 2^bits entries); prints its own JSON line")
     ap.add_argument("--no-parity", action="store_true",
                     help="skip the parity gate (only for timing experiments with builds that write no results)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -195,6 +198,43 @@ def main():
             "pcie_gbs": round((d_in.numel() + out_bytes) * args.steps / elapsed / 1e9, 2),
             "config": {"workload": "%s: %d pages x %d values, bit width %d, page-locked host buffers" %
                        (args.workload, my_pages, n, bits)}}), flush=True)
+        ctx.close()
+        return
+
+    if args.gather_bytes:  # decode + dictionary gather, device-resident
+        from parquet2_amd import DICT_REF_DTYPE
+        words = args.gather_bytes // 4
+        table = torch.randint(-2**31, 2**31 - 1, ((1 << bits) * words,), dtype=torch.int32, device=dev)
+        refs = np.zeros(my_pages, dtype=DICT_REF_DTYPE)
+        refs["dict_len"] = 1 << bits
+        d_val = torch.empty(my_pages * n * words, dtype=torch.int32, device=dev)
+
+        def gstep(want_status=False):
+            return ctx.decode_dict_batch_device(d_in.data_ptr(), d_in.numel(), descs, table.data_ptr(),
+                                                table.numel() * 4, refs, args.gather_bytes, d_val.data_ptr(),
+                                                my_pages * n, stream, want_status=want_status)
+
+        assert (gstep(True) == 0).all()
+        t2 = table.view(1 << bits, words)
+        for i in range(min(my_pages, len(pages))):
+            idx = torch.from_numpy(pages[(lo + i) % len(pages)][1].astype(np.int64)).to(dev)
+            assert torch.equal(d_val.view(my_pages, n, words)[i], t2[idx]), "gathered values differ on page %d" % i
+        for _ in range(args.warmup):
+            gstep()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            gstep()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        vbytes = my_pages * n * args.gather_bytes
+        print(json.dumps({
+            "metric": "device-resident dictionary decode + gather GB/s (value bytes out)",
+            "value": round(vbytes * args.steps / elapsed / 1e9, 2), "unit": "GB/s", "n_gpus": 1, "steps": args.steps,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "values_per_second": round(my_pages * n * args.steps / elapsed / 1e9, 3),
+            "config": {"workload": "%s: %d pages x %d values, bit width %d, %d-byte dictionary values" %
+                       (args.workload, my_pages, n, bits, args.gather_bytes)}}), flush=True)
         ctx.close()
         return
 

@@ -121,6 +121,36 @@ int32_t pq2_fetch_status(pq2_ctx *ctx, int32_t *status, uint64_t n_pages);
 int32_t pq2_decode_batch_host(pq2_ctx *ctx, const void *h_in, uint64_t in_bytes, const pq2_page_desc *descs,
                               uint64_t n_pages, uint32_t *h_out, uint64_t out_values, int32_t *status);
 
+/* ---- dictionary pages: indices -> values ---------------------------------- */
+
+/* Where a page's dictionary lies inside the dictionary buffer: `dict_len`
+ * PLAIN-encoded little-endian values of `value_size` bytes each from byte
+ * `dict_off` on (a decompressed dictionary page's buffer as it is:
+ * tests/it/read/dictionary/primitive.rs:30-50, src/types.rs:135-141).  Pages of
+ * one column chunk share one dictionary. */
+typedef struct pq2_dict_ref {
+    uint64_t dict_off; /* multiple of 8 for 8-byte values, of 4 otherwise */
+    uint32_t dict_len; /* entries */
+    uint32_t reserved;
+} pq2_dict_ref;
+
+/* Decodes the dictionary indices of a batch of pages as
+ * pq2_decode_batch_device does and replaces every index by its dictionary
+ * value: what a consumer does with NativePageState::RequiredDictionary /
+ * OptionalDictionary (src/deserialize/native.rs:28-69; the consumer loop
+ * `dict.indexes.map(|x| dict.dict.value(x))`, tests/it/read/primitive.rs:99-108).
+ * `value_size` is 4 (i32, f32), 8 (i64, f64) or 12 (int96); page i's values go to
+ * d_out + descs[i].out_off * value_size (d_out 8-byte aligned).  The indices
+ * pass through a buffer the context owns.  An index that is not below
+ * dict_len is Error::OutOfSpec in the reference
+ * (tests/it/read/dictionary/primitive.rs:20-27): the page gets status
+ * PQ2_OUT_OF_SPEC (unless the index stream itself already failed) and the
+ * value written for that index is zero. */
+int32_t pq2_decode_dict_batch_device(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const pq2_page_desc *descs,
+                                     uint64_t n_pages, const void *d_dict, uint64_t dict_bytes,
+                                     const pq2_dict_ref *dicts, uint32_t value_size, void *d_out, uint64_t out_values,
+                                     int32_t *status, void *stream);
+
 /* ---- plain bit-unpacking -------------------------------------------------- */
 
 /* Replaces bitpacked::Decoder::<u32>::try_new(packed, num_bits, length)?.collect()

@@ -34,6 +34,10 @@ PAGE_DESC_DTYPE = np.dtype([("in_off", "<u8"), ("in_len", "<u4"), ("num_bits", "
                             ("out_off", "<u8")])
 assert PAGE_DESC_DTYPE.itemsize == C.sizeof(PageDesc) == 32
 
+# pq2_dict_ref
+DICT_REF_DTYPE = np.dtype([("dict_off", "<u8"), ("dict_len", "<u4"), ("reserved", "<u4")])
+assert DICT_REF_DTYPE.itemsize == 16
+
 
 class Split(C.Structure):
     """pq2_split"""
@@ -57,6 +61,9 @@ SIGNATURES = {
     "pq2_decode_batch_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p,
                                              C.c_uint64, C.c_void_p, C.c_void_p]),
     "pq2_fetch_status": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64]),
+    "pq2_decode_dict_batch_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p,
+                                                  C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p,
+                                                  C.c_void_p]),
     "pq2_decode_batch_host": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p,
                                            C.c_uint64, C.c_void_p]),
     "pq2_bitunpack_u32_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p,
@@ -161,6 +168,21 @@ class Context:
         st = lib().pq2_decode_batch_device(self._h, C.c_void_p(d_in_ptr), in_bytes, ptr(descs), len(descs),
                                            C.c_void_p(d_out_ptr), out_values,
                                            ptr(status) if want_status else None, C.c_void_p(stream))
+        self._check(st)
+        return status
+
+    def decode_dict_batch_device(self, d_in_ptr, in_bytes, descs, d_dict_ptr, dict_bytes, dict_refs, value_size,
+                                 d_out_ptr, out_values, stream=0, want_status=True):
+        """Indices -> dictionary values on the device (pq2_decode_dict_batch_device).  descs: PAGE_DESC_DTYPE,
+        dict_refs: DICT_REF_DTYPE, one per page."""
+        descs = np.ascontiguousarray(descs, dtype=PAGE_DESC_DTYPE)
+        dict_refs = np.ascontiguousarray(dict_refs, dtype=DICT_REF_DTYPE)
+        assert len(dict_refs) == len(descs)
+        status = np.zeros(len(descs), dtype=np.int32) if want_status else None
+        st = lib().pq2_decode_dict_batch_device(self._h, C.c_void_p(d_in_ptr), in_bytes, ptr(descs), len(descs),
+                                                C.c_void_p(d_dict_ptr), dict_bytes, ptr(dict_refs), value_size,
+                                                C.c_void_p(d_out_ptr), out_values,
+                                                ptr(status) if want_status else None, C.c_void_p(stream))
         self._check(st)
         return status
 

@@ -31,6 +31,9 @@ hipError_t pq2_launch_bitunpack(const void *d_packed, uint32_t packed_len, uint3
 hipError_t pq2_launch_decode(const void *pages, uint32_t n_pages, void *resume, uint32_t *run_pos, int32_t *status,
                              void *state, uint32_t *cu_tickets, uint32_t max_bits, hipStream_t stream);
 uint32_t pq2_cu_ticket_bytes();
+hipError_t pq2_launch_gather(const void *pages, uint32_t n_pages, uint32_t n_tiles, uint32_t value_words,
+                             uint64_t max_dict_bytes, int32_t *status, hipStream_t stream);
+uint32_t pq2_gather_tile_values();
 }
 
 namespace {
@@ -62,6 +65,12 @@ struct DevBuf {
     size_t cap = 0;
 };
 
+struct GatherPage {  // must match pq2::GatherPage
+    uint64_t idx_addr, out_addr, dict_addr;
+    uint32_t dict_len, num_values, first_tile, reserved;
+};
+static_assert(sizeof(GatherPage) == 40, "GatherPage layout");
+
 }  // namespace
 
 struct pq2_ctx {
@@ -74,6 +83,12 @@ struct pq2_ctx {
     bool meta_in_flight = false;
     DevBuf d_meta, d_status, d_resume, d_tile_page, d_run_pos, d_state;
     DevBuf d_tickets;  // decode_kernel's per-compute-unit counters (zeroed once; only their low bits matter)
+    // pq2_decode_dict_batch_device: the decoded indices, and the per-page gather descriptors (page-locked + device)
+    DevBuf d_indices, d_gather;
+    void *h_gather = nullptr;
+    size_t h_gather_cap = 0;
+    hipEvent_t gather_copied = nullptr;
+    bool gather_in_flight = false;
     // Where the rounds of a page end, as fractions of its tiles (the last round ends with the page).  The parts
     // grow because round r + 1 is parsed while round r is expanded, and parsing is the faster of the two; the
     // first part is small because nothing hides its parse.  Tuning knobs: PQ2_ROUND_SPLIT="a,b,c",
@@ -404,7 +419,7 @@ int32_t pq2_ctx_destroy(pq2_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     for (DevBuf *b : {&ctx->d_meta, &ctx->d_status, &ctx->d_resume, &ctx->d_tile_page, &ctx->d_run_pos, &ctx->d_state,
-                      &ctx->d_tickets, &ctx->d_in, &ctx->d_out})
+                      &ctx->d_tickets, &ctx->d_indices, &ctx->d_gather, &ctx->d_in, &ctx->d_out})
         if (b->ptr) (void)hipFree(b->ptr);
     for (hipStream_t s : {ctx->parse_stream, ctx->expand_stream[0], ctx->expand_stream[1]})
         if (s) (void)hipStreamDestroy(s);
@@ -412,6 +427,8 @@ int32_t pq2_ctx_destroy(pq2_ctx *ctx) {
                          ctx->expand_joined[0], ctx->expand_joined[1]})
         if (e) (void)hipEventDestroy(e);
     if (ctx->h_meta) (void)hipHostFree(ctx->h_meta);
+    if (ctx->h_gather) (void)hipHostFree(ctx->h_gather);
+    if (ctx->gather_copied) (void)hipEventDestroy(ctx->gather_copied);
     if (ctx->meta_copied) (void)hipEventDestroy(ctx->meta_copied);
     for (auto &s : ctx->stamps) {
         (void)hipEventDestroy(s.begin);
@@ -479,6 +496,72 @@ int32_t pq2_decode_batch_device(pq2_ctx *ctx, const void *d_in, uint64_t in_byte
     PQ2_HIP(ctx, hipSetDevice(ctx->device));
     int32_t st = enqueue_batch(ctx, d_in, in_bytes, descs, n_pages, d_out, out_values, static_cast<hipStream_t>(stream));
     if (st != PQ2_OK) return st;
+    if (status) return fetch_status(ctx, status, n_pages);
+    return PQ2_OK;
+}
+
+int32_t pq2_decode_dict_batch_device(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const pq2_page_desc *descs,
+                                     uint64_t n_pages, const void *d_dict, uint64_t dict_bytes,
+                                     const pq2_dict_ref *dicts, uint32_t value_size, void *d_out, uint64_t out_values,
+                                     int32_t *status, void *stream_) {
+    if (!ctx) return PQ2_INVALID_PARAMETER;
+    PQ2_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (value_size != 4 && value_size != 8 && value_size != 12)
+        return fail(ctx, PQ2_INVALID_PARAMETER, "value_size must be 4, 8 or 12");
+    if (n_pages > 0 && !dicts) return fail(ctx, PQ2_INVALID_PARAMETER, "dicts is NULL");
+    if ((reinterpret_cast<uintptr_t>(d_out) & 7u) != 0 || (reinterpret_cast<uintptr_t>(d_dict) & 7u) != 0)
+        return fail(ctx, PQ2_INVALID_PARAMETER, "d_out / d_dict misaligned");
+    const uint64_t align = value_size == 8 ? 8 : 4;
+    for (uint64_t i = 0; i < n_pages; ++i) {
+        const pq2_dict_ref &r = dicts[i];
+        if (r.dict_off % align != 0) return fail(ctx, PQ2_INVALID_PARAMETER, "dictionary offset misaligned");
+        if (r.dict_off > dict_bytes || uint64_t(r.dict_len) * value_size > dict_bytes - r.dict_off)
+            return fail(ctx, PQ2_INVALID_PARAMETER, "dictionary outside the dictionary buffer");
+    }
+    int32_t st;
+    if (ctx->busy && ctx->last_stream != stream) PQ2_HIP(ctx, hipStreamSynchronize(ctx->last_stream));
+    if ((st = reserve(ctx, ctx->d_indices, std::max<uint64_t>(out_values, 1) * sizeof(uint32_t)))) return st;
+    uint32_t *d_idx = static_cast<uint32_t *>(ctx->d_indices.ptr);
+    if ((st = enqueue_batch(ctx, d_in, in_bytes, descs, n_pages, d_idx, out_values, stream))) return st;
+    if (n_pages > 0) {
+        const size_t bytes = n_pages * sizeof(GatherPage);
+        if (ctx->gather_in_flight) {  // the previous batch's upload still reads the page-locked block
+            PQ2_HIP(ctx, hipEventSynchronize(ctx->gather_copied));
+            ctx->gather_in_flight = false;
+        }
+        if (bytes > ctx->h_gather_cap) {
+            if (ctx->h_gather) PQ2_HIP(ctx, hipHostFree(ctx->h_gather));
+            ctx->h_gather = nullptr;
+            ctx->h_gather_cap = 0;
+            const size_t cap = (std::max(bytes, ctx->h_gather_cap * 2) + 4095) & ~size_t(4095);
+            PQ2_HIP(ctx, hipHostMalloc(&ctx->h_gather, cap, hipHostMallocDefault));
+            ctx->h_gather_cap = cap;
+        }
+        if (!ctx->gather_copied) PQ2_HIP(ctx, hipEventCreateWithFlags(&ctx->gather_copied, hipEventDisableTiming));
+        if ((st = reserve(ctx, ctx->d_gather, bytes))) return st;
+        GatherPage *g = static_cast<GatherPage *>(ctx->h_gather);
+        uint64_t tiles = 0, max_dict_bytes = 0;
+        const uint64_t kGatherTileValues = pq2_gather_tile_values();
+        for (uint64_t i = 0; i < n_pages; ++i) {
+            const pq2_page_desc &d = descs[i];
+            max_dict_bytes = std::max<uint64_t>(max_dict_bytes, uint64_t(dicts[i].dict_len) * value_size);
+            g[i].idx_addr = reinterpret_cast<uint64_t>(d_idx) + d.out_off * sizeof(uint32_t);
+            g[i].out_addr = reinterpret_cast<uint64_t>(d_out) + d.out_off * value_size;
+            g[i].dict_addr = reinterpret_cast<uint64_t>(d_dict) + dicts[i].dict_off;
+            g[i].dict_len = dicts[i].dict_len;
+            g[i].num_values = ctx->host_status[i] == PQ2_OK ? static_cast<uint32_t>(d.num_values) : 0u;
+            g[i].first_tile = static_cast<uint32_t>(tiles);
+            g[i].reserved = 0;
+            tiles += (uint64_t(g[i].num_values) + kGatherTileValues - 1) / kGatherTileValues;
+        }
+        PQ2_HIP(ctx, hipMemcpyAsync(ctx->d_gather.ptr, ctx->h_gather, bytes, hipMemcpyHostToDevice, stream));
+        PQ2_HIP(ctx, hipEventRecord(ctx->gather_copied, stream));
+        ctx->gather_in_flight = true;
+        PQ2_HIP(ctx, pq2_launch_gather(ctx->d_gather.ptr, static_cast<uint32_t>(n_pages), static_cast<uint32_t>(tiles),
+                                       value_size / 4, max_dict_bytes, static_cast<int32_t *>(ctx->d_status.ptr),
+                                       stream));
+    }
     if (status) return fetch_status(ctx, status, n_pages);
     return PQ2_OK;
 }

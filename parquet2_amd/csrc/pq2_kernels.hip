@@ -956,6 +956,96 @@ __global__ __launch_bounds__(256) void bitunpack_kernel(uint64_t in_addr, uint32
 
 }  // namespace pq2
 
+namespace pq2 {
+
+// ---------------------------------------------------------------------------
+// gather_kernel: dictionary indices -> dictionary values (the consumer loop of
+// a dictionary-encoded page: tests/it/read/primitive.rs:99-108, with
+// PrimitivePageDict::value, tests/it/read/dictionary/primitive.rs:20-27: an
+// index that is not below the dictionary's length is an error of the page).
+// One workgroup per 4096 values of one page; kWords dwords per value.
+// ---------------------------------------------------------------------------
+struct GatherPage {  // must match the host's
+    uint64_t idx_addr;   // the page's decoded indices (u32)
+    uint64_t out_addr;   // the page's values
+    uint64_t dict_addr;  // the page's dictionary
+    uint32_t dict_len;
+    uint32_t num_values;
+    uint32_t first_tile;  // batch-wide number of the page's first 4096-value tile
+    uint32_t reserved;
+};
+
+constexpr uint32_t kGatherTileValues = 65536;  // values of one page per workgroup of gather_kernel
+
+// kLds: the page's dictionary (at most `lds_bytes`) is copied into LDS first and the lookups go there: a wave's
+// 64 lookups at unrelated addresses take the vector cache one address at a time, LDS serves them by bank.
+template <int kWords, bool kLds>
+__global__ __launch_bounds__(256) void gather_kernel(const GatherPage *__restrict__ pages, uint32_t n_pages,
+                                                     int32_t *__restrict__ status, uint32_t lds_bytes) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    // the last page whose first tile is not behind this one (pages without values share their successor's)
+    const uint32_t tile = blockIdx.x;
+    uint32_t lo = 0, hi = n_pages;  // pages[lo].first_tile <= tile < pages[hi].first_tile
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (pages[mid].first_tile <= tile) lo = mid; else hi = mid;
+    }
+    const GatherPage pg = pages[lo];
+    const uint32_t first = (tile - pg.first_tile) * kGatherTileValues;
+    if (first >= pg.num_values) return;
+    const uint32_t count = min(kGatherTileValues, pg.num_values - first);
+    typedef __attribute__((address_space(1))) const uint32_t gu32;
+    typedef __attribute__((address_space(1))) const u32x4 gu32x4;
+    gu32 *const idx = (gu32 *)pg.idx_addr + first;
+    gu32 *const dict = (gu32 *)pg.dict_addr;
+    out_u32 *const out = (out_u32 *)pg.out_addr + (size_t)first * kWords;
+    const bool in_lds = kLds && (size_t)pg.dict_len * kWords * 4u <= lds_bytes;  // the same for the whole workgroup
+    if (in_lds) {
+        const uint32_t words = pg.dict_len * kWords;
+        for (uint32_t i = threadIdx.x; i < words; i += 256u) ((uint32_t *)lds)[i] = dict[i];
+        __syncthreads();
+    }
+    bool bad = false;
+    auto value_word = [&](uint32_t j, bool ok, int c) -> uint32_t {
+        if (!ok) return 0u;
+        return in_lds ? ((const uint32_t *)lds)[j * kWords + c] : dict[(size_t)j * kWords + c];
+    };
+    // Four values per thread and step where the page's indices and values are 16-byte aligned (every load and
+    // store a dwordx4); otherwise, and for the last values of the page, one value per thread.
+    uint32_t done = 0;
+    if (((pg.idx_addr | pg.out_addr) & 15u) == 0u) {
+        const uint32_t quads = count >> 2;
+#pragma unroll 2
+        for (uint32_t q = threadIdx.x; q < quads; q += 256u) {
+            const u32x4 j = ((gu32x4 *)idx)[q];
+            const bool ok[4] = {j.x < pg.dict_len, j.y < pg.dict_len, j.z < pg.dict_len, j.w < pg.dict_len};
+            bad |= !(ok[0] & ok[1] & ok[2] & ok[3]);
+            const uint32_t jj[4] = {j.x, j.y, j.z, j.w};
+            uint32_t v[4 * kWords];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int c = 0; c < kWords; ++c) v[k * kWords + c] = value_word(jj[k], ok[k], c);
+#pragma unroll
+            for (int c = 0; c < kWords; ++c) {
+                const u32x4 o = {v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]};
+                *((out_u32x4 *)out + (size_t)q * kWords + c) = o;
+            }
+        }
+        done = quads << 2;
+    }
+    for (uint32_t i = done + threadIdx.x; i < count; i += 256u) {
+        const uint32_t j = idx[i];
+        const bool ok = j < pg.dict_len;
+        bad |= !ok;
+#pragma unroll
+        for (int c = 0; c < kWords; ++c) out[(size_t)i * kWords + c] = value_word(j, ok, c);
+    }
+    if (__ballot(bad) != 0 && (threadIdx.x & 63u) == 0u) atomicCAS(&status[lo], 0, 1);  // PQ2_OUT_OF_SPEC
+}
+
+}  // namespace pq2
+
 // ---- launchers (called from pq2_api.cpp) ----------------------------------------
 extern "C" hipError_t pq2_launch_parse(const void *pages, uint32_t n_pages, void *resume, uint32_t *tile_page,
                                        uint32_t *run_pos, int32_t *status, void *state, uint32_t round,
@@ -1018,6 +1108,33 @@ extern "C" hipError_t pq2_launch_decode(const void *pages, uint32_t n_pages, voi
         hipLaunchKernelGGL(pq2::decode_kernel<false>, dim3(n_pages), dim3(256), lds_bytes, stream,
                            (const pq2::PageDev *)pages, n_pages, (pq2::Resume *)resume, run_pos, status,
                            (pq2::ParseState *)state, cu_tickets, win_bytes, pow2 * 8u - 1u);
+    return hipGetLastError();
+}
+
+extern "C" uint32_t pq2_gather_tile_values() { return pq2::kGatherTileValues; }
+
+// `max_dict_bytes`: the largest dictionary of the batch; dictionaries of up to 48 KiB are looked up in LDS.
+extern "C" hipError_t pq2_launch_gather(const void *pages, uint32_t n_pages, uint32_t n_tiles, uint32_t value_words,
+                                        uint64_t max_dict_bytes, int32_t *status, hipStream_t stream) {
+    if (n_tiles == 0) return hipSuccess;
+    const pq2::GatherPage *p = (const pq2::GatherPage *)pages;
+    const bool use_lds = max_dict_bytes > 0 && max_dict_bytes <= 49152u;
+    const uint32_t lds = use_lds ? (uint32_t)((max_dict_bytes + 15u) & ~15ull) : 0u;
+#define PQ2_GATHER(WORDS)                                                                                         \
+    if (use_lds)                                                                                                  \
+        hipLaunchKernelGGL((pq2::gather_kernel<WORDS, true>), dim3(n_tiles), dim3(256), lds, stream, p, n_pages,  \
+                           status, lds);                                                                          \
+    else                                                                                                          \
+        hipLaunchKernelGGL((pq2::gather_kernel<WORDS, false>), dim3(n_tiles), dim3(256), 0, stream, p, n_pages,   \
+                           status, 0u);
+    if (value_words == 1) {
+        PQ2_GATHER(1)
+    } else if (value_words == 2) {
+        PQ2_GATHER(2)
+    } else {
+        PQ2_GATHER(3)
+    }
+#undef PQ2_GATHER
     return hipGetLastError();
 }
 

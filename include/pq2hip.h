@@ -163,6 +163,16 @@ int32_t pq2_bitunpack_u32_device(pq2_ctx *ctx, const void *d_packed, uint64_t pa
 int32_t pq2_bitunpack_u32_host(pq2_ctx *ctx, const void *packed, uint64_t packed_len, uint32_t num_bits,
                                uint64_t length, uint32_t *out);
 
+/* The same for T = u64: bitpacked::Decoder::<u64>::try_new(packed, num_bits, length)?.collect()
+ * (decode.rs:28-86 with Unpackable for u64, src/encoding/bitpacked/mod.rs:153-166; unpack64,
+ * unpack.rs:21-95), num_bits 1..64 -- what DELTA_BINARY_PACKED mini-blocks are made of
+ * (src/encoding/delta_bitpacked/decoder.rs:85).  d_out 8-byte aligned.  num_bits > 64 ->
+ * PQ2_REFERENCE_WOULD_PANIC. */
+int32_t pq2_bitunpack_u64_device(pq2_ctx *ctx, const void *d_packed, uint64_t packed_len, uint32_t num_bits,
+                                 uint64_t length, uint64_t *d_out, void *stream);
+int32_t pq2_bitunpack_u64_host(pq2_ctx *ctx, const void *packed, uint64_t packed_len, uint32_t num_bits,
+                               uint64_t length, uint64_t *out);
+
 /* ---- multi-GPU sharding ---------------------------------------------------- */
 
 /* Splits a batch into `n_parts` contiguous page ranges balanced on output

@@ -69,6 +69,9 @@ SIGNATURES = {
     "pq2_bitunpack_u32_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p,
                                               C.c_void_p]),
     "pq2_bitunpack_u32_host": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p]),
+    "pq2_bitunpack_u64_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p,
+                                              C.c_void_p]),
+    "pq2_bitunpack_u64_host": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p]),
     "pq2_partition_pages": (C.c_int32, [C.c_void_p, C.c_uint64, C.c_uint32, u64p]),
     "pq2_ceil8": (C.c_uint64, [C.c_uint64]),
     "pq2_get_length": (C.c_int32, [C.c_void_p, C.c_uint64, u64p]),
@@ -223,6 +226,18 @@ class Context:
         st = lib().pq2_bitunpack_u32_host(self._h, ptr(packed), packed.size, num_bits, length, ptr(out))
         self._check(st)
         return out if packed.size else out[:0]
+
+    def bitunpack_u64_host(self, packed, num_bits, length):
+        """bitpacked::Decoder::<u64>::try_new(packed, num_bits, length)?.collect()"""
+        packed = as_u8(packed)
+        out = np.zeros(length, dtype=np.uint64)
+        st = lib().pq2_bitunpack_u64_host(self._h, ptr(packed), packed.size, num_bits, length, ptr(out))
+        self._check(st)
+        return out if packed.size else out[:0]
+
+    def bitunpack_u64_device(self, d_packed_ptr, packed_len, num_bits, length, d_out_ptr, stream=0):
+        self._check(lib().pq2_bitunpack_u64_device(self._h, C.c_void_p(d_packed_ptr), packed_len, num_bits, length,
+                                                   C.c_void_p(d_out_ptr), C.c_void_p(stream)))
 
     def bitunpack_u32_device(self, d_packed_ptr, packed_len, num_bits, length, d_out_ptr, stream=0):
         self._check(lib().pq2_bitunpack_u32_device(self._h, C.c_void_p(d_packed_ptr), packed_len, num_bits, length,

@@ -34,6 +34,8 @@ uint32_t pq2_cu_ticket_bytes();
 hipError_t pq2_launch_gather(const void *pages, uint32_t n_pages, uint32_t n_tiles, uint32_t value_words,
                              uint64_t max_dict_bytes, int32_t *status, hipStream_t stream);
 uint32_t pq2_gather_tile_values();
+hipError_t pq2_launch_bitunpack64(const void *d_packed, uint32_t packed_len, uint32_t num_bits, uint32_t length,
+                                  uint64_t *d_out, hipStream_t stream);
 }
 
 namespace {
@@ -730,7 +732,8 @@ int32_t pq2_decode_batch_host(pq2_ctx *ctx, const void *h_in, uint64_t in_bytes,
     return PQ2_OK;
 }
 
-static int32_t check_bitunpack(pq2_ctx *ctx, uint64_t packed_len, uint32_t num_bits, uint64_t *length) {
+static int32_t check_bitunpack(pq2_ctx *ctx, uint64_t packed_len, uint32_t num_bits, uint64_t *length,
+                               uint32_t max_bits = 32) {
     // src/encoding/bitpacked/decode.rs:30-50, in the reference's order
     if (num_bits == 0) return fail(ctx, PQ2_OUT_OF_SPEC, "Bitpacking requires num_bits > 0");
     if (static_cast<unsigned __int128>(packed_len) * 8 < static_cast<unsigned __int128>(*length) * num_bits)
@@ -738,7 +741,7 @@ static int32_t check_bitunpack(pq2_ctx *ctx, uint64_t packed_len, uint32_t num_b
                                                std::to_string(num_bits) + " requires at least " +
                                                std::to_string(*length * num_bits / 8) + " bytes.");
     if (packed_len == 0) *length = 0;
-    if (num_bits > 32 && packed_len > 0) return fail(ctx, PQ2_REFERENCE_WOULD_PANIC, "invalid num_bits");
+    if (num_bits > max_bits && packed_len > 0) return fail(ctx, PQ2_REFERENCE_WOULD_PANIC, "invalid num_bits");
     if (packed_len > PQ2_MAX_PAGE_BYTES || *length > PQ2_MAX_PAGE_VALUES)
         return fail(ctx, PQ2_INVALID_PARAMETER, "buffer too large for one call");
     return PQ2_OK;
@@ -770,6 +773,36 @@ int32_t pq2_bitunpack_u32_host(pq2_ctx *ctx, const void *packed, uint64_t packed
     PQ2_HIP(ctx, pq2_launch_bitunpack(ctx->d_in.ptr, static_cast<uint32_t>(packed_len), num_bits,
                                       static_cast<uint32_t>(length), static_cast<uint32_t *>(ctx->d_out.ptr), s));
     PQ2_HIP(ctx, hipMemcpyAsync(out, ctx->d_out.ptr, length * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    PQ2_HIP(ctx, hipStreamSynchronize(s));
+    return PQ2_OK;
+}
+
+int32_t pq2_bitunpack_u64_device(pq2_ctx *ctx, const void *d_packed, uint64_t packed_len, uint32_t num_bits,
+                                 uint64_t length, uint64_t *d_out, void *stream) {
+    if (!ctx) return PQ2_INVALID_PARAMETER;
+    PQ2_HIP(ctx, hipSetDevice(ctx->device));
+    int32_t st = check_bitunpack(ctx, packed_len, num_bits, &length, 64);
+    if (st != PQ2_OK) return st;
+    if ((reinterpret_cast<uintptr_t>(d_out) & 7u) != 0) return fail(ctx, PQ2_INVALID_PARAMETER, "d_out misaligned");
+    PQ2_HIP(ctx, pq2_launch_bitunpack64(d_packed, static_cast<uint32_t>(packed_len), num_bits,
+                                        static_cast<uint32_t>(length), d_out, static_cast<hipStream_t>(stream)));
+    return PQ2_OK;
+}
+
+int32_t pq2_bitunpack_u64_host(pq2_ctx *ctx, const void *packed, uint64_t packed_len, uint32_t num_bits,
+                               uint64_t length, uint64_t *out) {
+    if (!ctx) return PQ2_INVALID_PARAMETER;
+    PQ2_HIP(ctx, hipSetDevice(ctx->device));
+    int32_t st = check_bitunpack(ctx, packed_len, num_bits, &length, 64);
+    if (st != PQ2_OK) return st;
+    if (length == 0) return PQ2_OK;
+    if ((st = reserve(ctx, ctx->d_in, packed_len + 16))) return st;
+    if ((st = reserve(ctx, ctx->d_out, length * sizeof(uint64_t)))) return st;
+    hipStream_t s = nullptr;
+    PQ2_HIP(ctx, hipMemcpyAsync(ctx->d_in.ptr, packed, packed_len, hipMemcpyHostToDevice, s));
+    PQ2_HIP(ctx, pq2_launch_bitunpack64(ctx->d_in.ptr, static_cast<uint32_t>(packed_len), num_bits,
+                                        static_cast<uint32_t>(length), static_cast<uint64_t *>(ctx->d_out.ptr), s));
+    PQ2_HIP(ctx, hipMemcpyAsync(out, ctx->d_out.ptr, length * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     PQ2_HIP(ctx, hipStreamSynchronize(s));
     return PQ2_OK;
 }

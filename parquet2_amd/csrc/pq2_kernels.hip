@@ -1044,6 +1044,31 @@ __global__ __launch_bounds__(256) void gather_kernel(const GatherPage *__restric
     if (__ballot(bad) != 0 && (threadIdx.x & 63u) == 0u) atomicCAS(&status[lo], 0, 1);  // PQ2_OUT_OF_SPEC
 }
 
+// ---------------------------------------------------------------------------
+// bitunpack64_kernel: `length` values of width w (1..64) from a bit-packed
+// buffer into u64 (bitpacked::Decoder<u64>, decode.rs:28-86; unpack64,
+// unpack.rs:21-95: LSB-first fields of a little-endian byte stream).  One value
+// per thread and step: three aligned dwords, two funnel shifts, a mask.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bitunpack64_kernel(uint64_t in_addr, uint32_t in_len, uint32_t w,
+                                                          uint32_t length, uint64_t *__restrict__ out) {
+    const uint32_t delta = (uint32_t)(in_addr & 15u);
+    const uint32_t end = delta + in_len;
+    const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(in_addr - delta, (end + 3u) & ~3u);
+    const uint64_t mask = w == 64u ? ~0ull : ((1ull << w) - 1ull);
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < length; i += gridDim.x * 256u) {
+        const uint64_t bit = (uint64_t)delta * 8u + (uint64_t)i * w;
+        const uint32_t d = (uint32_t)(bit >> 5) * 4u;  // byte offset of the first dword (the buffer is < 4 GiB)
+        const uint32_t sh = (uint32_t)bit & 31u;
+        const uint32_t x0 = __builtin_amdgcn_raw_buffer_load_b32(rsrc, d, 0, 0);
+        const uint32_t x1 = __builtin_amdgcn_raw_buffer_load_b32(rsrc, d + 4u, 0, 0);
+        const uint32_t x2 = __builtin_amdgcn_raw_buffer_load_b32(rsrc, d + 8u, 0, 0);
+        const uint32_t lo = __builtin_amdgcn_alignbit(x1, x0, sh);
+        const uint32_t hi = __builtin_amdgcn_alignbit(x2, x1, sh);
+        out[i] = (((uint64_t)hi << 32) | lo) & mask;
+    }
+}
+
 }  // namespace pq2
 
 // ---- launchers (called from pq2_api.cpp) ----------------------------------------
@@ -1108,6 +1133,15 @@ extern "C" hipError_t pq2_launch_decode(const void *pages, uint32_t n_pages, voi
         hipLaunchKernelGGL(pq2::decode_kernel<false>, dim3(n_pages), dim3(256), lds_bytes, stream,
                            (const pq2::PageDev *)pages, n_pages, (pq2::Resume *)resume, run_pos, status,
                            (pq2::ParseState *)state, cu_tickets, win_bytes, pow2 * 8u - 1u);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t pq2_launch_bitunpack64(const void *d_packed, uint32_t packed_len, uint32_t num_bits,
+                                             uint32_t length, uint64_t *d_out, hipStream_t stream) {
+    if (length == 0) return hipSuccess;
+    const uint32_t blocks = (length + 255u) / 256u;
+    hipLaunchKernelGGL(pq2::bitunpack64_kernel, dim3(blocks < 65536u ? blocks : 65536u), dim3(256), 0, stream,
+                       (uint64_t)(uintptr_t)d_packed, packed_len, num_bits, length, d_out);
     return hipGetLastError();
 }
 

@@ -10,18 +10,23 @@ from ..error import raise_for_status
 
 
 class Decoder:
-    """`bitpacked::Decoder::<u32>::try_new(packed, num_bits, length)` (decode.rs:28-86).
+    """`bitpacked::Decoder::<T>::try_new(packed, num_bits, length)` (decode.rs:28-86), T = u32 (the default) or
+    u64 (`dtype=np.uint64`: `Unpackable for u64`, mod.rs:153-166).
 
     The values are unpacked eagerly on the GPU; iterating yields Python ints,
-    `collect()` returns the uint32 ndarray.
+    `collect()` returns the ndarray.
     """
 
-    def __init__(self, packed, num_bits, length, ctx=None):
+    def __init__(self, packed, num_bits, length, ctx=None, dtype=np.uint32):
         ctx = ctx or default_context()
-        self._values = ctx.bitunpack_u32_host(packed, num_bits, length)
+        if np.dtype(dtype) == np.uint64:
+            self._values = ctx.bitunpack_u64_host(packed, num_bits, length)
+        else:
+            self._values = ctx.bitunpack_u32_host(packed, num_bits, length)
         self._pos = 0
 
-    try_new = classmethod(lambda cls, packed, num_bits, length, ctx=None: cls(packed, num_bits, length, ctx))
+    try_new = classmethod(lambda cls, packed, num_bits, length, ctx=None, dtype=np.uint32:
+                          cls(packed, num_bits, length, ctx, dtype))
 
     def collect(self):
         return self._values[self._pos:]

@@ -3,7 +3,7 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One step = one pass of the decoder (pq2_decode_batch_device: parse + expand kernels) over one batch of
+One step = one pass of the decoder (pq2_decode_batch_device: decode_kernel, or parse + expand kernels) over one batch of
 synthetic RLE_DICTIONARY index pages already resident in HBM: `--pages` pages per GPU of 2^20 values, bit
 width 12, mixed RLE / bit-packed runs (BASELINE.json configs[1]; the default of 2048 pages per GPU is the per-GPU
 share of configs[4]).  With N > 1 the script runs under
@@ -289,16 +289,19 @@ def main():
         # a batch is decoded in `rounds` launches of each kernel, every launch covering 1/rounds of every page
         rounds = max(expand_launches // max(batches, 1), 1)
         expand_avg_ms = expand_ms / max(expand_launches, 1)
+        # batches of many pages go through decode_kernel alone (one workgroup per page walks and expands);
+        # the context times that launch in the place of expand_kernel's
+        kernel_name = "decode_kernel" if parse_ms == 0.0 else "expand_kernel"
         bytes_per_launch = (in_bytes_alg + out_bytes) / rounds
         achieved = bytes_per_launch / (expand_avg_ms * 1e-3) / 1e9
-        # HBM bytes of expand_kernel from the PMC passes recorded for this workload (FETCH_SIZE / WRITE_SIZE cannot be
+        # HBM bytes of that kernel from the PMC passes recorded for this workload (FETCH_SIZE / WRITE_SIZE cannot be
         # collected from inside the process)
         traffic = None
         try:
             t = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_traffic.json")))
             if t["workload"] == {"workload": args.workload, "pages_per_gpu": args.pages, "values_per_page": n,
                                  "num_bits": bits}:
-                e = t["expand_kernel"]
+                e = t[kernel_name]
                 traffic = (e["fetch_bytes_per_step"] + e["write_bytes_per_step"]) // rounds
         except (OSError, KeyError, ValueError):
             pass
@@ -316,12 +319,12 @@ def main():
                 "sharding": "pages partitioned across ranks, no collective",
             },
             "roofline": {
-                "bound": "hbm", "kernel": "expand_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": int(bytes_per_launch),
                 "avg_launch_ms": round(expand_avg_ms, 4), "launches_per_step": rounds,
                 "parse_kernel_ms_per_step": round(parse_ms / max(batches, 1), 4),
-                "expand_kernel_ms_per_step": round(expand_ms / max(batches, 1), 4),
+                "%s_ms_per_step" % kernel_name: round(expand_ms / max(batches, 1), 4),
             },
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -45,9 +45,7 @@ constexpr uint32_t kBlocksPerTile = 4;
 constexpr uint32_t kRounds = 4;          // must match pq2::kRounds
 constexpr uint64_t kMinRoundedTiles = 16384;  // batches below 64 Mi values are decoded in one round
 constexpr size_t kParseStateBytes = 16;  // sizeof(pq2::ParseState)
-// batches of at least this many pages whose pages average at most that many values take one workgroup per page
-constexpr uint64_t kFusedMinPages = 64;
-constexpr uint64_t kFusedMaxPageValues = 1ull << 18;
+constexpr uint64_t kFusedMinPages = 64;  // batches of at least this many pages take one workgroup per page
 
 struct PageDev {  // must match pq2::PageDev
     uint64_t in_addr;
@@ -199,7 +197,7 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
     }
     PageDev *pages = static_cast<PageDev *>(ctx->h_meta);
 
-    uint64_t tiles = 0, run_entries = 0, total_values = 0;
+    uint64_t tiles = 0, run_entries = 0;
     uint32_t max_bits = 0;  // over the pages that are decoded
     for (uint64_t i = 0; i < n_pages; ++i) {
         const pq2_page_desc &d = descs[i];
@@ -227,16 +225,14 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
         p.run_base = run_entries;
         run_entries += (std::min<uint64_t>(p.num_values, d.in_len / 2) + 1 + 64 + 63) & ~uint64_t(63);
         tiles += page_tiles;
-        total_values += p.num_values;
         if (tiles > 0x7fffffffull) return fail(ctx, PQ2_INVALID_PARAMETER, "batch too large for one launch");
     }
     if ((reinterpret_cast<uintptr_t>(d_out) & 3u) != 0) return fail(ctx, PQ2_INVALID_PARAMETER, "d_out misaligned");
 
-    // many pages of moderate size: the per-page kernel has every walk running from the start and nothing of a
-    // page waits for other pages; few or very large pages: tiles of all pages share the whole GPU
-    const bool per_page = ctx->mode == pq2_ctx::kPerPage ||
-                          (ctx->mode == pq2_ctx::kAuto && n_pages >= kFusedMinPages &&
-                           total_values <= n_pages * kFusedMaxPageValues);
+    // enough pages to fill the GPU with one workgroup each: the per-page kernel has every walk running from the
+    // start, nothing of a page waits for other pages, and the stream comes out of the cache the second time it is
+    // read; fewer pages: the tiles of all pages share the whole GPU
+    const bool per_page = ctx->mode == pq2_ctx::kPerPage || (ctx->mode == pq2_ctx::kAuto && n_pages >= kFusedMinPages);
     // tiles are numbered round-major: all tiles of round 0 of all pages, then round 1, ...
     const bool split = !per_page && tiles >= ctx->min_rounded_tiles;
     // Nothing hides the parse of the first part, and the walk of a page takes the same time whatever the batch

@@ -245,6 +245,7 @@ __device__ __forceinline__ void parse_page(const PageDev &pg, const uint32_t pag
     }
 
     uint32_t pos = ps.pos;  // a-offset of the next header
+    uint32_t announce = 0;  // values covered by the entries of the passes before the last one (0: nothing to announce)
     for (;;) {
         // ---- chase: park up to 64 runs, record i in lane i --------------------------------------------
         uint32_t r_pos = 0, r_lo = 0, r_hi = 0, r_info = 0;
@@ -299,6 +300,8 @@ __device__ __forceinline__ void parse_page(const PageDev &pg, const uint32_t pag
             if (m == 64u) break;
         }
 
+        // what the previous pass stored has had this pass's chase to reach memory: announcing it now costs no wait
+        if (announce != 0u) publish(announce);
         // ---- place: lane i decodes record i; a prefix sum over the run lengths places the runs -------------
         uint32_t kind, count, info, after;  // after: a-offset of the byte behind an RLE run
         {
@@ -365,7 +368,7 @@ __device__ __forceinline__ void parse_page(const PageDev &pg, const uint32_t pag
             return;
         }
         if (produced >= target) break;
-        publish(produced);
+        announce = produced;
     }
     if (lane == 0) {
         ParseState out;
@@ -859,6 +862,10 @@ __global__ __launch_bounds__(256, PQ2_EXPAND_WAVES) void expand_kernel(const Pag
 // ---------------------------------------------------------------------------
 constexpr uint32_t kDecodeExpanders = 3;
 constexpr uint32_t kMaxPolls = 1u << 24;  // of about 0.1 us each: far beyond the longest header walk of a page
+#ifndef PQ2_LEAD_TILES
+#define PQ2_LEAD_TILES 5
+#endif
+constexpr uint32_t kLeadTiles = PQ2_LEAD_TILES;  // tiles the walk may be ahead of the expansion (0: no limit)
 constexpr uint32_t kCuTickets = 4096;     // entries of the per-compute-unit ticket table (see decode_kernel)
 // Which wave of the workgroup walks the headers.  The walk issues an instruction whenever its SIMD lets it, and
 // the workgroups that share a compute unit would all put wave 0 on the same SIMD, where the walks would take
@@ -895,13 +902,31 @@ __global__ __launch_bounds__(256, 4) void decode_kernel(const PageDev *__restric
     const PageDev pg = pages[page];
     uint8_t *const tables = lds + kWin + kDecodeExpanders * win_bytes + 32u;
     uint32_t *const parsed = (uint32_t *)(tables + kDecodeExpanders * ((kTableRuns + 2) * 8u + kChunkSlots * 4u));
-    if (threadIdx.x == 0) *parsed = 0u;
+    if (threadIdx.x < 4u) parsed[threadIdx.x] = 0u;  // the progress word; tiles done by each expanding wave
     const uint32_t walker = pick_walker(cu_tickets, parsed + 4, wave, lane);  // with a workgroup barrier inside
 
     if (wave == walker) {
+        // (pages whose stream is small beside their values -- long RLE runs -- have nothing to keep in the cache)
+        const bool throttled = pg.in_len / 512u >= (pg.num_values + kTileValues - 1u) / kTileValues;
         parse_page<kWide>(pg, page, lds, resume, nullptr, run_pos, status, state, 0u, lane, [&](uint32_t covered) {
             // release: the entries stored before are visible to whoever sees the new number
             if (lane == 0) __hip_atomic_store(parsed, covered, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // The walk does not run further ahead of the expansion than kLeadTiles tiles: the expanding waves read
+            // the stream a second time, and what lies between the two reads of a byte (of all pages resident on
+            // the GPU, with the values written meanwhile) has to fit the last-level cache for the second read not
+            // to reach memory.  The wave that holds the lowest unfinished tile never waits for the walk here
+            // (the walk is past that tile by at least one tile), so the wait ends; it is bounded all the same.
+            if (kLeadTiles != 0u && throttled && covered != kAllParsed) {
+                for (uint32_t polls = 0; polls < kMaxPolls; ++polls) {
+                    uint32_t lowest = 0xffffffffu;  // the lowest tile some expanding wave has not finished
+#pragma unroll
+                    for (uint32_t k = 0; k < kDecodeExpanders; ++k)
+                        lowest = min(lowest, k + kDecodeExpanders * __hip_atomic_load(parsed + 1u + k, __ATOMIC_RELAXED,
+                                                                                       __HIP_MEMORY_SCOPE_WORKGROUP));
+                    if (covered / kTileValues <= lowest + kLeadTiles) break;
+                    __builtin_amdgcn_s_sleep(8);
+                }
+            }
         });
         return;
     }
@@ -931,6 +956,10 @@ __global__ __launch_bounds__(256, 4) void decode_kernel(const PageDev *__restric
         }
         expand_page_tile<true>(pg, rs4, t * kTileValues, run_pos, lds + kWin + e * win_bytes, win_bytes, win_bit_mask,
                                tbl, cidx, lane);
+        // (no release: the walk only counts tiles with this, and a wider fence would wait for the stores to drain)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        if (lane == 0)
+            __hip_atomic_store(parsed + 1u + e, t / kDecodeExpanders + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 }
 

@@ -151,6 +151,34 @@ int32_t pq2_decode_dict_batch_device(pq2_ctx *ctx, const void *d_in, uint64_t in
                                      const pq2_dict_ref *dicts, uint32_t value_size, void *d_out, uint64_t out_values,
                                      int32_t *status, void *stream);
 
+/* Optional (nullable) dictionary-encoded pages of a flat column: decodes the
+ * definition levels (def_descs[i]: the page's level stream, num_bits =
+ * get_bit_width(max_def_levels[i]), num_values = rows) and the dictionary
+ * indices (idx_descs[i]: num_bits = the page's index width, num_values = the
+ * page header's num_values; its out_off is ignored), and writes for every row
+ * r of page i, at d_out + (def_descs[i].out_off + r) * value_size and
+ * d_validity + def_descs[i].out_off + r:
+ *   level[r] == max_def_levels[i]: the dictionary value of the page's next unused
+ *                                  index, validity 1;
+ *   otherwise:                     zero, validity 0.
+ * This is deserialize_optional over DefLevelsDecoder::Levels and
+ * OptionalDictionary (src/deserialize/utils.rs:41-57, native.rs:28-69; the
+ * consumer tests/it/read/utils.rs:7-66 with tests/it/read/primitive.rs:104-110):
+ * indices are consumed by valid rows only, so an index beyond the dictionary
+ * fails the page (PQ2_OUT_OF_SPEC) only if a valid row consumes it, and a
+ * valid row behind the last index is null (`values.next()` is None).  For
+ * max_def_level 1 the reference takes the levels as bitmap runs
+ * (DefLevelsDecoder::Bitmap), which yields the same rows except that a level
+ * stream that ends early yields fewer rows there and null rows here.
+ * status[i]: the level stream's status if not OK, else the index stream's,
+ * else PQ2_OUT_OF_SPEC for a consumed index beyond the dictionary. */
+int32_t pq2_decode_optional_dict_batch_device(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes,
+                                              const pq2_page_desc *def_descs, const pq2_page_desc *idx_descs,
+                                              const uint32_t *max_def_levels, uint64_t n_pages, const void *d_dict,
+                                              uint64_t dict_bytes, const pq2_dict_ref *dicts, uint32_t value_size,
+                                              void *d_out, uint8_t *d_validity, uint64_t out_rows, int32_t *status,
+                                              void *stream);
+
 /* ---- plain bit-unpacking -------------------------------------------------- */
 
 /* Replaces bitpacked::Decoder::<u32>::try_new(packed, num_bits, length)?.collect()

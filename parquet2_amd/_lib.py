@@ -69,6 +69,10 @@ SIGNATURES = {
     "pq2_bitunpack_u32_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p,
                                               C.c_void_p]),
     "pq2_bitunpack_u32_host": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p]),
+    "pq2_decode_optional_dict_batch_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
+                                                           C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p,
+                                                           C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
+                                                           C.c_void_p]),
     "pq2_bitunpack_u64_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p,
                                               C.c_void_p]),
     "pq2_bitunpack_u64_host": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p]),
@@ -186,6 +190,23 @@ class Context:
                                                 C.c_void_p(d_dict_ptr), dict_bytes, ptr(dict_refs), value_size,
                                                 C.c_void_p(d_out_ptr), out_values,
                                                 ptr(status) if want_status else None, C.c_void_p(stream))
+        self._check(st)
+        return status
+
+    def decode_optional_dict_batch_device(self, d_in_ptr, in_bytes, def_descs, idx_descs, max_def_levels, d_dict_ptr,
+                                          dict_bytes, dict_refs, value_size, d_out_ptr, d_validity_ptr, out_rows,
+                                          stream=0, want_status=True):
+        """Nullable dictionary pages -> values + validity bytes (pq2_decode_optional_dict_batch_device)."""
+        def_descs = np.ascontiguousarray(def_descs, dtype=PAGE_DESC_DTYPE)
+        idx_descs = np.ascontiguousarray(idx_descs, dtype=PAGE_DESC_DTYPE)
+        dict_refs = np.ascontiguousarray(dict_refs, dtype=DICT_REF_DTYPE)
+        max_def_levels = np.ascontiguousarray(max_def_levels, dtype=np.uint32)
+        assert len(def_descs) == len(idx_descs) == len(dict_refs) == len(max_def_levels)
+        status = np.zeros(len(def_descs), dtype=np.int32) if want_status else None
+        st = lib().pq2_decode_optional_dict_batch_device(
+            self._h, C.c_void_p(d_in_ptr), in_bytes, ptr(def_descs), ptr(idx_descs), ptr(max_def_levels),
+            len(def_descs), C.c_void_p(d_dict_ptr), dict_bytes, ptr(dict_refs), value_size, C.c_void_p(d_out_ptr),
+            C.c_void_p(d_validity_ptr), out_rows, ptr(status) if want_status else None, C.c_void_p(stream))
         self._check(st)
         return status
 

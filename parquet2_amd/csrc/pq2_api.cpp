@@ -34,6 +34,8 @@ uint32_t pq2_cu_ticket_bytes();
 hipError_t pq2_launch_gather(const void *pages, uint32_t n_pages, uint32_t n_tiles, uint32_t value_words,
                              uint64_t max_dict_bytes, int32_t *status, hipStream_t stream);
 uint32_t pq2_gather_tile_values();
+hipError_t pq2_launch_optional(const void *pages, uint32_t n_pages, uint32_t value_words, int32_t *status,
+                               hipStream_t stream);
 hipError_t pq2_launch_bitunpack64(const void *d_packed, uint32_t packed_len, uint32_t num_bits, uint32_t length,
                                   uint64_t *d_out, hipStream_t stream);
 }
@@ -70,6 +72,12 @@ struct GatherPage {  // must match pq2::GatherPage
     uint32_t dict_len, num_values, first_tile, reserved;
 };
 static_assert(sizeof(GatherPage) == 40, "GatherPage layout");
+
+struct OptionalPage {  // must match pq2::OptionalPage
+    uint64_t level_addr, idx_addr, out_addr, validity_addr, dict_addr;
+    uint32_t rows, idx_values, dict_len, max_level, idx_status_at, reserved;
+};
+static_assert(sizeof(OptionalPage) == 64, "OptionalPage layout");
 
 }  // namespace
 
@@ -560,6 +568,92 @@ int32_t pq2_decode_dict_batch_device(pq2_ctx *ctx, const void *d_in, uint64_t in
                                        value_size / 4, max_dict_bytes, static_cast<int32_t *>(ctx->d_status.ptr),
                                        stream));
     }
+    if (status) return fetch_status(ctx, status, n_pages);
+    return PQ2_OK;
+}
+
+int32_t pq2_decode_optional_dict_batch_device(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes,
+                                              const pq2_page_desc *def_descs, const pq2_page_desc *idx_descs,
+                                              const uint32_t *max_def_levels, uint64_t n_pages, const void *d_dict,
+                                              uint64_t dict_bytes, const pq2_dict_ref *dicts, uint32_t value_size,
+                                              void *d_out, uint8_t *d_validity, uint64_t out_rows, int32_t *status,
+                                              void *stream_) {
+    if (!ctx) return PQ2_INVALID_PARAMETER;
+    PQ2_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (value_size != 4 && value_size != 8 && value_size != 12)
+        return fail(ctx, PQ2_INVALID_PARAMETER, "value_size must be 4, 8 or 12");
+    if (n_pages > 0x3fffffffull) return fail(ctx, PQ2_INVALID_PARAMETER, "too many pages in one batch");
+    if (n_pages > 0 && (!def_descs || !idx_descs || !max_def_levels || !dicts))
+        return fail(ctx, PQ2_INVALID_PARAMETER, "a descriptor array is NULL");
+    if ((reinterpret_cast<uintptr_t>(d_out) & 3u) != 0 || (reinterpret_cast<uintptr_t>(d_dict) & 3u) != 0)
+        return fail(ctx, PQ2_INVALID_PARAMETER, "d_out / d_dict misaligned");
+    // the level and index streams of all pages as one batch of 2 * n_pages streams decoded into the context's buffer
+    std::vector<pq2_page_desc> both(2 * n_pages);
+    uint64_t at = 0;
+    for (uint64_t i = 0; i < n_pages; ++i) {
+        const pq2_dict_ref &r = dicts[i];
+        if (r.dict_off % 4 != 0) return fail(ctx, PQ2_INVALID_PARAMETER, "dictionary offset misaligned");
+        if (r.dict_off > dict_bytes || uint64_t(r.dict_len) * value_size > dict_bytes - r.dict_off)
+            return fail(ctx, PQ2_INVALID_PARAMETER, "dictionary outside the dictionary buffer");
+        if (def_descs[i].out_off > out_rows || def_descs[i].num_values > out_rows - def_descs[i].out_off)
+            return fail(ctx, PQ2_INVALID_PARAMETER, "page rows outside the output buffer");
+        both[i] = def_descs[i];
+        both[i].out_off = at;
+        at += (def_descs[i].num_values + 3) & ~uint64_t(3);  // every page's levels start 16-byte aligned
+    }
+    for (uint64_t i = 0; i < n_pages; ++i) {
+        both[n_pages + i] = idx_descs[i];
+        both[n_pages + i].out_off = at;
+        at += (idx_descs[i].num_values + 3) & ~uint64_t(3);
+    }
+    int32_t st;
+    if (ctx->busy && ctx->last_stream != stream) PQ2_HIP(ctx, hipStreamSynchronize(ctx->last_stream));
+    if ((st = reserve(ctx, ctx->d_indices, std::max<uint64_t>(at, 1) * sizeof(uint32_t)))) return st;
+    uint32_t *d_scratch = static_cast<uint32_t *>(ctx->d_indices.ptr);
+    if ((st = enqueue_batch(ctx, d_in, in_bytes, both.data(), 2 * n_pages, d_scratch, at, stream))) return st;
+    if (n_pages > 0) {
+        const size_t bytes = n_pages * sizeof(OptionalPage);
+        if (ctx->gather_in_flight) {
+            PQ2_HIP(ctx, hipEventSynchronize(ctx->gather_copied));
+            ctx->gather_in_flight = false;
+        }
+        if (bytes > ctx->h_gather_cap) {
+            if (ctx->h_gather) PQ2_HIP(ctx, hipHostFree(ctx->h_gather));
+            ctx->h_gather = nullptr;
+            ctx->h_gather_cap = 0;
+            const size_t cap = (bytes + 4095) & ~size_t(4095);
+            PQ2_HIP(ctx, hipHostMalloc(&ctx->h_gather, cap, hipHostMallocDefault));
+            ctx->h_gather_cap = cap;
+        }
+        if (!ctx->gather_copied) PQ2_HIP(ctx, hipEventCreateWithFlags(&ctx->gather_copied, hipEventDisableTiming));
+        if ((st = reserve(ctx, ctx->d_gather, bytes))) return st;
+        OptionalPage *g = static_cast<OptionalPage *>(ctx->h_gather);
+        for (uint64_t i = 0; i < n_pages; ++i) {
+            const bool skip = ctx->host_status[i] != PQ2_OK || ctx->host_status[n_pages + i] != PQ2_OK;
+            g[i].level_addr = reinterpret_cast<uint64_t>(d_scratch + both[i].out_off);
+            g[i].idx_addr = reinterpret_cast<uint64_t>(d_scratch + both[n_pages + i].out_off);
+            g[i].out_addr = reinterpret_cast<uint64_t>(d_out) + def_descs[i].out_off * value_size;
+            g[i].validity_addr = reinterpret_cast<uint64_t>(d_validity) + def_descs[i].out_off;
+            g[i].dict_addr = reinterpret_cast<uint64_t>(d_dict) + dicts[i].dict_off;
+            g[i].rows = skip ? 0u : static_cast<uint32_t>(def_descs[i].num_values);
+            g[i].idx_values = static_cast<uint32_t>(idx_descs[i].num_values);
+            g[i].dict_len = dicts[i].dict_len;
+            g[i].max_level = max_def_levels[i];
+            g[i].idx_status_at = static_cast<uint32_t>(n_pages + i);
+            g[i].reserved = 0;
+        }
+        PQ2_HIP(ctx, hipMemcpyAsync(ctx->d_gather.ptr, ctx->h_gather, bytes, hipMemcpyHostToDevice, stream));
+        PQ2_HIP(ctx, hipEventRecord(ctx->gather_copied, stream));
+        ctx->gather_in_flight = true;
+        PQ2_HIP(ctx, pq2_launch_optional(ctx->d_gather.ptr, static_cast<uint32_t>(n_pages), value_size / 4,
+                                         static_cast<int32_t *>(ctx->d_status.ptr), stream));
+        // from here on the batch has n_pages statuses: a page's own, or else its index stream's
+        for (uint64_t i = 0; i < n_pages; ++i)
+            if (ctx->host_status[i] == PQ2_OK) ctx->host_status[i] = ctx->host_status[n_pages + i];
+        ctx->host_status.resize(n_pages);
+    }
+    ctx->last_n_pages = n_pages;
     if (status) return fetch_status(ctx, status, n_pages);
     return PQ2_OK;
 }

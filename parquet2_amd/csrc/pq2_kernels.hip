@@ -1074,6 +1074,134 @@ __global__ __launch_bounds__(256) void gather_kernel(const GatherPage *__restric
 }
 
 // ---------------------------------------------------------------------------
+// optional_kernel: definition levels + dictionary indices -> nullable values
+// (deserialize_levels, tests/it/read/utils.rs:52-66, over an OptionalDictionary
+// page, tests/it/read/primitive.rs:104-110): row r is valid where its level
+// equals the maximum, and the k-th valid row takes the dictionary value of the
+// page's k-th index.  One workgroup per page walks the page's rows 1024 at a
+// time (four consecutive rows per thread), carrying the count of valid rows: a
+// prefix sum over the lanes of a wave, the four wave totals through LDS.
+// ---------------------------------------------------------------------------
+struct OptionalPage {  // must match the host's
+    uint64_t level_addr;  // decoded levels (u32), one per row; 16-byte aligned
+    uint64_t idx_addr;    // decoded indices (u32)
+    uint64_t out_addr, validity_addr, dict_addr;
+    uint32_t rows, idx_values, dict_len, max_level;
+    uint32_t idx_status_at;  // where the index stream's status lies in the status array
+    uint32_t reserved;
+};
+
+template <int kWords>
+__global__ __launch_bounds__(256) void optional_kernel(const OptionalPage *__restrict__ pages, uint32_t n_pages,
+                                                       int32_t *__restrict__ status) {
+    __shared__ uint32_t wave_total[2][4];
+    const uint32_t page = blockIdx.x;
+    if (page >= n_pages) return;
+    const OptionalPage pg = pages[page];
+    typedef __attribute__((address_space(1))) const uint32_t gu32;
+    typedef __attribute__((address_space(1))) const u32x4 gu32x4;
+    gu32 *const level = (gu32 *)pg.level_addr;
+    gu32 *const idx = (gu32 *)pg.idx_addr;
+    gu32 *const dict = (gu32 *)pg.dict_addr;
+    out_u32 *const out = (out_u32 *)pg.out_addr;
+    __attribute__((address_space(1))) uint8_t *const validity =
+        (__attribute__((address_space(1))) uint8_t *)pg.validity_addr;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    uint32_t used = 0;  // valid rows before this step = indices consumed
+    bool bad = false;
+    uint32_t flip = 0;
+    // the four levels of rows r0 .. r0 + 3 (rows behind the page's end: a level that is not the maximum)
+    auto load_levels = [&](uint32_t r0) {
+        u32x4 lv = {~pg.max_level, ~pg.max_level, ~pg.max_level, ~pg.max_level};
+        if (r0 + 3u < pg.rows) {
+            lv = ((gu32x4 *)level)[r0 >> 2];
+        } else {
+            if (r0 < pg.rows) lv.x = level[r0];
+            if (r0 + 1u < pg.rows) lv.y = level[r0 + 1u];
+            if (r0 + 2u < pg.rows) lv.z = level[r0 + 2u];
+        }
+        return lv;
+    };
+    // whole quads of rows are written with one store each where the page's values and validity bytes are aligned
+    const bool aligned = ((pg.out_addr & 15u) | (pg.validity_addr & 3u)) == 0u;
+    u32x4 lv_next = load_levels(4u * threadIdx.x);
+    for (uint32_t base = 0; base < pg.rows; base += 1024u, flip ^= 1u) {
+        const uint32_t r0 = base + 4u * threadIdx.x;
+        const u32x4 lv = lv_next;
+        lv_next = load_levels(r0 + 1024u);  // the next step's levels are on their way while this step works
+        const uint32_t l4[4] = {lv.x, lv.y, lv.z, lv.w};
+        bool v[4];
+        uint32_t c = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) {
+            v[k] = r0 + k < pg.rows && l4[k] == pg.max_level;
+            c += v[k] ? 1u : 0u;
+        }
+        const uint32_t incl = wave_inclusive_sum(c);
+        if (lane == 63u) wave_total[flip][wave] = incl;
+        __syncthreads();  // (the other buffer is written in the next step, this one again only after that step's barrier)
+        uint32_t below = 0, all = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) {
+            const uint32_t t = wave_total[flip][k];
+            below += k < wave ? t : 0u;
+            all += t;
+        }
+        uint32_t rank = used + below + incl - c;
+        bool present[4];
+        uint32_t j[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) {
+            present[k] = v[k] && rank < pg.idx_values;  // behind the last index: values.next() is None
+            j[k] = 0;
+            if (present[k]) j[k] = idx[rank];
+            rank += v[k] ? 1u : 0u;
+        }
+        uint32_t val[4][kWords];
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) {
+            const bool ok = j[k] < pg.dict_len;
+            bad |= present[k] && !ok;
+#pragma unroll
+            for (int w = 0; w < kWords; ++w) val[k][w] = 0u;
+            if (present[k] && ok) {
+#pragma unroll
+                for (int w = 0; w < kWords; ++w) val[k][w] = dict[(size_t)j[k] * kWords + w];
+            }
+        }
+        if (aligned && r0 + 3u < pg.rows) {
+            uint32_t flat[4 * kWords];
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k)
+#pragma unroll
+                for (int w = 0; w < kWords; ++w) flat[k * kWords + w] = val[k][w];
+#pragma unroll
+            for (int w = 0; w < kWords; ++w) {
+                const u32x4 o = {flat[4 * w], flat[4 * w + 1], flat[4 * w + 2], flat[4 * w + 3]};
+                *((out_u32x4 *)out + (size_t)(r0 >> 2) * kWords + w) = o;
+            }
+            *(__attribute__((address_space(1))) uint32_t *)(validity + r0) =
+                (present[0] ? 1u : 0u) | (present[1] ? 0x100u : 0u) | (present[2] ? 0x10000u : 0u) |
+                (present[3] ? 0x1000000u : 0u);
+        } else {
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k) {
+                if (r0 + k >= pg.rows) break;
+#pragma unroll
+                for (int w = 0; w < kWords; ++w) out[(size_t)(r0 + k) * kWords + w] = val[k][w];
+                validity[r0 + k] = present[k] ? 1 : 0;
+            }
+        }
+        used += all;
+    }
+    const int any_bad = __syncthreads_or(bad ? 1 : 0);
+    if (threadIdx.x == 0 && status[page] == 0) {
+        const int32_t of_indices = status[pg.idx_status_at];
+        status[page] = of_indices != 0 ? of_indices : (any_bad ? 1 : 0);  // PQ2_OUT_OF_SPEC
+    }
+}
+
+// ---------------------------------------------------------------------------
 // bitunpack64_kernel: `length` values of width w (1..64) from a bit-packed
 // buffer into u64 (bitpacked::Decoder<u64>, decode.rs:28-86; unpack64,
 // unpack.rs:21-95: LSB-first fields of a little-endian byte stream).  One value
@@ -1162,6 +1290,19 @@ extern "C" hipError_t pq2_launch_decode(const void *pages, uint32_t n_pages, voi
         hipLaunchKernelGGL(pq2::decode_kernel<false>, dim3(n_pages), dim3(256), lds_bytes, stream,
                            (const pq2::PageDev *)pages, n_pages, (pq2::Resume *)resume, run_pos, status,
                            (pq2::ParseState *)state, cu_tickets, win_bytes, pow2 * 8u - 1u);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t pq2_launch_optional(const void *pages, uint32_t n_pages, uint32_t value_words, int32_t *status,
+                                          hipStream_t stream) {
+    if (n_pages == 0) return hipSuccess;
+    const pq2::OptionalPage *p = (const pq2::OptionalPage *)pages;
+    if (value_words == 1)
+        hipLaunchKernelGGL(pq2::optional_kernel<1>, dim3(n_pages), dim3(256), 0, stream, p, n_pages, status);
+    else if (value_words == 2)
+        hipLaunchKernelGGL(pq2::optional_kernel<2>, dim3(n_pages), dim3(256), 0, stream, p, n_pages, status);
+    else
+        hipLaunchKernelGGL(pq2::optional_kernel<3>, dim3(n_pages), dim3(256), 0, stream, p, n_pages, status);
     return hipGetLastError();
 }
 

@@ -132,10 +132,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     distributed = world > 1
+    # PQ2_BENCH_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks (ranks share GPUs)
+    backend = os.environ.get("PQ2_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(torch.cuda.device_count(), 1)
     if distributed:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     elif args.gpus != 1:
         print("bench.py: --gpus %d needs `python -m torch.distributed.run --nproc-per-node %d ...`" %
               (args.gpus, args.gpus), file=sys.stderr)
@@ -274,10 +281,11 @@ def main():
     ctx.enable_profiling(False)
 
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        rdev = dev if backend == "nccl" else torch.device("cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        tot = torch.tensor([float(out_bytes)], dtype=torch.float64, device=dev)
+        tot = torch.tensor([float(out_bytes)], dtype=torch.float64, device=rdev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         total_out_bytes = float(tot.item())
     else:

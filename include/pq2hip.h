@@ -179,6 +179,30 @@ int32_t pq2_decode_optional_dict_batch_device(pq2_ctx *ctx, const void *d_in, ui
                                               void *d_out, uint8_t *d_validity, uint64_t out_rows, int32_t *status,
                                               void *stream);
 
+/* ---- selected rows ---------------------------------------------------------- */
+
+/* indexes::Interval (src/indexes/intervals.rs:11-16): `length` rows from row `start`. */
+typedef struct pq2_interval {
+    uint64_t start;
+    uint64_t length;
+} pq2_interval;
+
+/* SliceFilteredIter::new(HybridRleDecoder::try_new(...), selected_rows)
+ * (src/deserialize/utils.rs:92-148) for a batch of pages: page i keeps the
+ * values of its intervals intervals[interval_offsets[i] .. interval_offsets[i + 1]),
+ * one interval after the other, at d_out + descs[i].out_off (descs[i].num_values
+ * stays the page's full count; the caller lays the pages out by their selected
+ * counts).  The whole page is decoded into a buffer the context owns and the
+ * selected ranges are copied from there.  The reference's iterator needs
+ * ascending, non-overlapping intervals of at least one row (it subtracts
+ * without checking) and ends early at the page's end; here such a list, or an
+ * interval that reaches beyond num_values, makes the call fail with
+ * PQ2_INVALID_PARAMETER before anything is enqueued. */
+int32_t pq2_decode_selected_batch_device(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const pq2_page_desc *descs,
+                                         uint64_t n_pages, const pq2_interval *intervals,
+                                         const uint64_t *interval_offsets, uint32_t *d_out, uint64_t out_values,
+                                         int32_t *status, void *stream);
+
 /* ---- plain bit-unpacking -------------------------------------------------- */
 
 /* Replaces bitpacked::Decoder::<u32>::try_new(packed, num_bits, length)?.collect()

@@ -35,6 +35,8 @@ PAGE_DESC_DTYPE = np.dtype([("in_off", "<u8"), ("in_len", "<u4"), ("num_bits", "
 assert PAGE_DESC_DTYPE.itemsize == C.sizeof(PageDesc) == 32
 
 # pq2_dict_ref
+# pq2_interval
+INTERVAL_DTYPE = np.dtype([("start", "<u8"), ("length", "<u8")])
 DICT_REF_DTYPE = np.dtype([("dict_off", "<u8"), ("dict_len", "<u4"), ("reserved", "<u4")])
 assert DICT_REF_DTYPE.itemsize == 16
 
@@ -73,6 +75,9 @@ SIGNATURES = {
                                                            C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p,
                                                            C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
                                                            C.c_void_p]),
+    "pq2_decode_selected_batch_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+                                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
+                                                      C.c_void_p]),
     "pq2_bitunpack_u64_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p,
                                               C.c_void_p]),
     "pq2_bitunpack_u64_host": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p]),
@@ -207,6 +212,22 @@ class Context:
             self._h, C.c_void_p(d_in_ptr), in_bytes, ptr(def_descs), ptr(idx_descs), ptr(max_def_levels),
             len(def_descs), C.c_void_p(d_dict_ptr), dict_bytes, ptr(dict_refs), value_size, C.c_void_p(d_out_ptr),
             C.c_void_p(d_validity_ptr), out_rows, ptr(status) if want_status else None, C.c_void_p(stream))
+        self._check(st)
+        return status
+
+    def decode_selected_batch_device(self, d_in_ptr, in_bytes, descs, intervals, interval_offsets, d_out_ptr, out_values,
+                                     stream=0, want_status=True):
+        """SliceFilteredIter over every page's values (pq2_decode_selected_batch_device).  intervals: INTERVAL_DTYPE,
+        interval_offsets: n_pages + 1 indices into it."""
+        descs = np.ascontiguousarray(descs, dtype=PAGE_DESC_DTYPE)
+        intervals = np.ascontiguousarray(intervals, dtype=INTERVAL_DTYPE)
+        interval_offsets = np.ascontiguousarray(interval_offsets, dtype=np.uint64)
+        assert len(interval_offsets) == len(descs) + 1
+        status = np.zeros(len(descs), dtype=np.int32) if want_status else None
+        st = lib().pq2_decode_selected_batch_device(self._h, C.c_void_p(d_in_ptr), in_bytes, ptr(descs), len(descs),
+                                                    ptr(intervals), ptr(interval_offsets), C.c_void_p(d_out_ptr),
+                                                    out_values, ptr(status) if want_status else None,
+                                                    C.c_void_p(stream))
         self._check(st)
         return status
 

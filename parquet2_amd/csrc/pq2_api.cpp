@@ -34,6 +34,7 @@ uint32_t pq2_cu_ticket_bytes();
 hipError_t pq2_launch_gather(const void *pages, uint32_t n_pages, uint32_t n_tiles, uint32_t value_words,
                              uint64_t max_dict_bytes, int32_t *status, hipStream_t stream);
 uint32_t pq2_gather_tile_values();
+hipError_t pq2_launch_select(const void *pieces, uint32_t n_pieces, hipStream_t stream);
 hipError_t pq2_launch_optional(const void *pages, uint32_t n_pages, uint32_t value_words, int32_t *status,
                                hipStream_t stream);
 hipError_t pq2_launch_bitunpack64(const void *d_packed, uint32_t packed_len, uint32_t num_bits, uint32_t length,
@@ -78,6 +79,13 @@ struct OptionalPage {  // must match pq2::OptionalPage
     uint32_t rows, idx_values, dict_len, max_level, idx_status_at, reserved;
 };
 static_assert(sizeof(OptionalPage) == 64, "OptionalPage layout");
+
+struct SelectPiece {  // must match pq2::SelectPiece
+    uint64_t src_addr, dst_addr;
+    uint32_t count, reserved;
+};
+static_assert(sizeof(SelectPiece) == 24, "SelectPiece layout");
+constexpr uint64_t kSelectPieceValues = 16384;
 
 }  // namespace
 
@@ -654,6 +662,86 @@ int32_t pq2_decode_optional_dict_batch_device(pq2_ctx *ctx, const void *d_in, ui
         ctx->host_status.resize(n_pages);
     }
     ctx->last_n_pages = n_pages;
+    if (status) return fetch_status(ctx, status, n_pages);
+    return PQ2_OK;
+}
+
+int32_t pq2_decode_selected_batch_device(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const pq2_page_desc *descs,
+                                         uint64_t n_pages, const pq2_interval *intervals,
+                                         const uint64_t *interval_offsets, uint32_t *d_out, uint64_t out_values,
+                                         int32_t *status, void *stream_) {
+    if (!ctx) return PQ2_INVALID_PARAMETER;
+    PQ2_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (n_pages > 0 && (!descs || !interval_offsets)) return fail(ctx, PQ2_INVALID_PARAMETER, "an array is NULL");
+    if ((reinterpret_cast<uintptr_t>(d_out) & 3u) != 0) return fail(ctx, PQ2_INVALID_PARAMETER, "d_out misaligned");
+    // every page decoded in full into the context's buffer, 16-byte aligned
+    std::vector<pq2_page_desc> full(descs, descs + n_pages);
+    std::vector<SelectPiece> pieces;
+    uint64_t at = 0;
+    for (uint64_t i = 0; i < n_pages; ++i) {
+        full[i].out_off = at;
+        if (interval_offsets[i] > interval_offsets[i + 1])
+            return fail(ctx, PQ2_INVALID_PARAMETER, "interval_offsets must ascend");
+        if (interval_offsets[i] < interval_offsets[i + 1] && !intervals)
+            return fail(ctx, PQ2_INVALID_PARAMETER, "intervals is NULL");
+        uint64_t current = 0, selected = 0;  // SliceFilteredIter::current (utils.rs:101, 128-131)
+        for (uint64_t k = interval_offsets[i]; k < interval_offsets[i + 1]; ++k) {
+            const pq2_interval &iv = intervals[k];
+            if (iv.length == 0 || iv.start < current || iv.start > descs[i].num_values ||
+                iv.length > descs[i].num_values - iv.start)
+                return fail(ctx, PQ2_INVALID_PARAMETER,
+                            "intervals must hold at least one row, ascend without overlap and end inside the page");
+            current = iv.start + iv.length;
+            selected += iv.length;
+        }
+        if (descs[i].out_off > out_values || selected > out_values - descs[i].out_off)
+            return fail(ctx, PQ2_INVALID_PARAMETER, "selected rows outside the output buffer");
+        at += (descs[i].num_values + 3) & ~uint64_t(3);
+    }
+    int32_t st;
+    if (ctx->busy && ctx->last_stream != stream) PQ2_HIP(ctx, hipStreamSynchronize(ctx->last_stream));
+    if ((st = reserve(ctx, ctx->d_indices, std::max<uint64_t>(at, 1) * sizeof(uint32_t)))) return st;
+    uint32_t *d_full = static_cast<uint32_t *>(ctx->d_indices.ptr);
+    if ((st = enqueue_batch(ctx, d_in, in_bytes, full.data(), n_pages, d_full, at, stream))) return st;
+    for (uint64_t i = 0; i < n_pages; ++i) {
+        if (ctx->host_status[i] != PQ2_OK) continue;
+        uint64_t dst = descs[i].out_off;
+        for (uint64_t k = interval_offsets[i]; k < interval_offsets[i + 1]; ++k) {
+            for (uint64_t o = 0; o < intervals[k].length; o += kSelectPieceValues) {
+                SelectPiece pc;
+                pc.src_addr = reinterpret_cast<uint64_t>(d_full + full[i].out_off + intervals[k].start + o);
+                pc.dst_addr = reinterpret_cast<uint64_t>(d_out + dst + o);
+                pc.count = static_cast<uint32_t>(std::min<uint64_t>(kSelectPieceValues, intervals[k].length - o));
+                pc.reserved = 0;
+                pieces.push_back(pc);
+            }
+            dst += intervals[k].length;
+        }
+    }
+    if (pieces.size() > 0x7fffffffull) return fail(ctx, PQ2_INVALID_PARAMETER, "too many intervals in one batch");
+    if (!pieces.empty()) {
+        const size_t bytes = pieces.size() * sizeof(SelectPiece);
+        if (ctx->gather_in_flight) {
+            PQ2_HIP(ctx, hipEventSynchronize(ctx->gather_copied));
+            ctx->gather_in_flight = false;
+        }
+        if (bytes > ctx->h_gather_cap) {
+            if (ctx->h_gather) PQ2_HIP(ctx, hipHostFree(ctx->h_gather));
+            ctx->h_gather = nullptr;
+            ctx->h_gather_cap = 0;
+            const size_t cap = (bytes + 4095) & ~size_t(4095);
+            PQ2_HIP(ctx, hipHostMalloc(&ctx->h_gather, cap, hipHostMallocDefault));
+            ctx->h_gather_cap = cap;
+        }
+        if (!ctx->gather_copied) PQ2_HIP(ctx, hipEventCreateWithFlags(&ctx->gather_copied, hipEventDisableTiming));
+        if ((st = reserve(ctx, ctx->d_gather, bytes))) return st;
+        std::memcpy(ctx->h_gather, pieces.data(), bytes);
+        PQ2_HIP(ctx, hipMemcpyAsync(ctx->d_gather.ptr, ctx->h_gather, bytes, hipMemcpyHostToDevice, stream));
+        PQ2_HIP(ctx, hipEventRecord(ctx->gather_copied, stream));
+        ctx->gather_in_flight = true;
+        PQ2_HIP(ctx, pq2_launch_select(ctx->d_gather.ptr, static_cast<uint32_t>(pieces.size()), stream));
+    }
     if (status) return fetch_status(ctx, status, n_pages);
     return PQ2_OK;
 }

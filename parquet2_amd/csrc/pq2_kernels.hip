@@ -1202,6 +1202,31 @@ __global__ __launch_bounds__(256) void optional_kernel(const OptionalPage *__res
 }
 
 // ---------------------------------------------------------------------------
+// select_kernel: copies the selected row ranges of decoded pages to their places
+// (SliceFilteredIter, src/deserialize/utils.rs:92-148).  One workgroup per piece
+// of at most 16384 values of one interval.
+// ---------------------------------------------------------------------------
+struct SelectPiece {  // must match the host's
+    uint64_t src_addr, dst_addr;  // u32 values
+    uint32_t count, reserved;
+};
+
+__global__ __launch_bounds__(256) void select_kernel(const SelectPiece *__restrict__ pieces) {
+    const SelectPiece pc = pieces[blockIdx.x];
+    typedef __attribute__((address_space(1))) const uint32_t gu32;
+    typedef __attribute__((address_space(1))) const u32x4 gu32x4;
+    gu32 *const src = (gu32 *)pc.src_addr;
+    out_u32 *const dst = (out_u32 *)pc.dst_addr;
+    uint32_t done = 0;
+    if (((pc.src_addr | pc.dst_addr) & 15u) == 0u) {
+        const uint32_t quads = pc.count >> 2;
+        for (uint32_t q = threadIdx.x; q < quads; q += 256u) ((out_u32x4 *)dst)[q] = ((gu32x4 *)src)[q];
+        done = quads << 2;
+    }
+    for (uint32_t i = done + threadIdx.x; i < pc.count; i += 256u) dst[i] = src[i];
+}
+
+// ---------------------------------------------------------------------------
 // bitunpack64_kernel: `length` values of width w (1..64) from a bit-packed
 // buffer into u64 (bitpacked::Decoder<u64>, decode.rs:28-86; unpack64,
 // unpack.rs:21-95: LSB-first fields of a little-endian byte stream).  One value
@@ -1303,6 +1328,12 @@ extern "C" hipError_t pq2_launch_optional(const void *pages, uint32_t n_pages, u
         hipLaunchKernelGGL(pq2::optional_kernel<2>, dim3(n_pages), dim3(256), 0, stream, p, n_pages, status);
     else
         hipLaunchKernelGGL(pq2::optional_kernel<3>, dim3(n_pages), dim3(256), 0, stream, p, n_pages, status);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t pq2_launch_select(const void *pieces, uint32_t n_pieces, hipStream_t stream) {
+    if (n_pieces == 0) return hipSuccess;
+    hipLaunchKernelGGL(pq2::select_kernel, dim3(n_pieces), dim3(256), 0, stream, (const pq2::SelectPiece *)pieces);
     return hipGetLastError();
 }
 

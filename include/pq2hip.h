@@ -203,6 +203,43 @@ int32_t pq2_decode_selected_batch_device(pq2_ctx *ctx, const void *d_in, uint64_
                                          const uint64_t *interval_offsets, uint32_t *d_out, uint64_t out_values,
                                          int32_t *status, void *stream);
 
+/* ---- whole V1 data pages, split on the device -------------------------------- */
+
+/* A decompressed DataPage V1 buffer that lies in device memory (for instance
+ * behind a GPU decompressor), which the host therefore cannot slice:
+ * [u32 length][repetition levels] if max_rep_level > 0, [u32 length][definition
+ * levels] if max_def_level > 0, then the values (src/page/mod.rs:350-398,
+ * :414-420); for a dictionary-encoded page the values are [bit width][hybrid-RLE
+ * indices] (src/deserialize/utils.rs:13-27). */
+#define PQ2_RAW_DICT_INDICES 1u
+typedef struct pq2_raw_page {
+    uint64_t buf_off;       /* the page buffer inside d_buf */
+    uint32_t buf_len;
+    uint32_t num_values;    /* the page header's num_values */
+    uint16_t max_rep_level; /* of the column's descriptor */
+    uint16_t max_def_level;
+    uint32_t flags;         /* PQ2_RAW_DICT_INDICES: decode the values as dictionary indices */
+    uint64_t out_off;       /* the page's first value in each of the three outputs */
+} pq2_raw_page;
+
+/* split_buffer_v1 + get_bit_width + dict_indices_decoder on the device, then the
+ * decode of up to three streams per page: repetition levels to d_rep, definition
+ * levels to d_def (bit width get_bit_width(max level), src/read/levels.rs:3-5),
+ * dictionary indices to d_idx, num_values each at out_off.  An output whose
+ * stream no page has may be NULL.  `max_index_bits`: an upper bound of the pages'
+ * index widths (a dictionary of n entries needs at most get_bit_width(n - 1)
+ * bits; 0 = unknown, 32 is assumed, at the price of larger LDS windows).
+ * status[i], the first that applies: PQ2_OUT_OF_SPEC for a level length prefix
+ * that is missing or exceeds the buffer (page/mod.rs:358-391) or an index width
+ * above 32 (utils.rs:19-23); PQ2_REFERENCE_WOULD_PANIC for a dictionary page
+ * without values (utils.rs:18); PQ2_INVALID_PARAMETER for an index width above
+ * max_index_bits; else the statuses of the repetition, definition and index
+ * streams in this order.  The outputs of a page with a non-OK status are
+ * unspecified. */
+int32_t pq2_decode_raw_pages_v1_device(pq2_ctx *ctx, const void *d_buf, uint64_t buf_bytes, const pq2_raw_page *pages,
+                                       uint64_t n_pages, uint32_t max_index_bits, uint32_t *d_rep, uint32_t *d_def,
+                                       uint32_t *d_idx, uint64_t out_values, int32_t *status, void *stream);
+
 /* ---- plain bit-unpacking -------------------------------------------------- */
 
 /* Replaces bitpacked::Decoder::<u32>::try_new(packed, num_bits, length)?.collect()

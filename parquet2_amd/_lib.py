@@ -35,6 +35,11 @@ PAGE_DESC_DTYPE = np.dtype([("in_off", "<u8"), ("in_len", "<u4"), ("num_bits", "
 assert PAGE_DESC_DTYPE.itemsize == C.sizeof(PageDesc) == 32
 
 # pq2_dict_ref
+# pq2_raw_page
+RAW_PAGE_DTYPE = np.dtype([("buf_off", "<u8"), ("buf_len", "<u4"), ("num_values", "<u4"), ("max_rep_level", "<u2"),
+                           ("max_def_level", "<u2"), ("flags", "<u4"), ("out_off", "<u8")])
+assert RAW_PAGE_DTYPE.itemsize == 32
+RAW_DICT_INDICES = 1
 # pq2_interval
 INTERVAL_DTYPE = np.dtype([("start", "<u8"), ("length", "<u8")])
 DICT_REF_DTYPE = np.dtype([("dict_off", "<u8"), ("dict_len", "<u4"), ("reserved", "<u4")])
@@ -78,6 +83,9 @@ SIGNATURES = {
     "pq2_decode_selected_batch_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
                                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
                                                       C.c_void_p]),
+    "pq2_decode_raw_pages_v1_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32,
+                                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
+                                                    C.c_void_p]),
     "pq2_bitunpack_u64_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p,
                                               C.c_void_p]),
     "pq2_bitunpack_u64_host": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p]),
@@ -228,6 +236,18 @@ class Context:
                                                     ptr(intervals), ptr(interval_offsets), C.c_void_p(d_out_ptr),
                                                     out_values, ptr(status) if want_status else None,
                                                     C.c_void_p(stream))
+        self._check(st)
+        return status
+
+    def decode_raw_pages_v1_device(self, d_buf_ptr, buf_bytes, pages, max_index_bits, d_rep_ptr, d_def_ptr, d_idx_ptr,
+                                   out_values, stream=0):
+        """Whole decompressed V1 data page buffers in device memory -> repetition levels, definition levels and
+        dictionary indices (pq2_decode_raw_pages_v1_device).  pages: RAW_PAGE_DTYPE.  Returns the statuses."""
+        pages = np.ascontiguousarray(pages, dtype=RAW_PAGE_DTYPE)
+        status = np.zeros(len(pages), dtype=np.int32)
+        st = lib().pq2_decode_raw_pages_v1_device(self._h, C.c_void_p(d_buf_ptr), buf_bytes, ptr(pages), len(pages),
+                                                  max_index_bits, C.c_void_p(d_rep_ptr), C.c_void_p(d_def_ptr),
+                                                  C.c_void_p(d_idx_ptr), out_values, ptr(status), C.c_void_p(stream))
         self._check(st)
         return status
 

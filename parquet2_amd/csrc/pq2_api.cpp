@@ -34,6 +34,7 @@ uint32_t pq2_cu_ticket_bytes();
 hipError_t pq2_launch_gather(const void *pages, uint32_t n_pages, uint32_t n_tiles, uint32_t value_words,
                              uint64_t max_dict_bytes, int32_t *status, hipStream_t stream);
 uint32_t pq2_gather_tile_values();
+hipError_t pq2_launch_front(void *streams, const void *raw, uint32_t n_pages, int32_t *front_status, hipStream_t stream);
 hipError_t pq2_launch_select(const void *pieces, uint32_t n_pieces, hipStream_t stream);
 hipError_t pq2_launch_optional(const void *pages, uint32_t n_pages, uint32_t value_words, int32_t *status,
                                hipStream_t stream);
@@ -86,6 +87,19 @@ struct SelectPiece {  // must match pq2::SelectPiece
 };
 static_assert(sizeof(SelectPiece) == 24, "SelectPiece layout");
 constexpr uint64_t kSelectPieceValues = 16384;
+
+struct RawPageDev {  // must match pq2::RawPageDev
+    uint64_t buf_addr;
+    uint32_t buf_len, what;
+};
+static_assert(sizeof(RawPageDev) == 16, "RawPageDev layout");
+
+// What pq2_decode_raw_pages_v1_device adds to a batch: front_kernel patches the uploaded stream descriptors.
+struct FrontJob {
+    const void *d_raw;
+    uint32_t n_pages;
+    int32_t *d_front_status;
+};
 
 }  // namespace
 
@@ -192,7 +206,8 @@ int32_t reserve_pinned(pq2_ctx *ctx, size_t bytes) {
 // Validates the batch, builds the device descriptors in pinned memory, uploads
 // them and enqueues parse + expand on `stream`.
 int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const pq2_page_desc *descs, uint64_t n_pages,
-                      uint32_t *d_out, uint64_t out_values, hipStream_t stream) {
+                      uint32_t *d_out, uint64_t out_values, hipStream_t stream, const FrontJob *front = nullptr,
+                      uint32_t min_max_bits = 0) {
     if (n_pages > 0x7fffffffull) return fail(ctx, PQ2_INVALID_PARAMETER, "too many pages in one batch");
     if (n_pages > 0 && !descs) return fail(ctx, PQ2_INVALID_PARAMETER, "descs is NULL");
     // the device-side metadata and the Resume table are shared by consecutive batches: stream order
@@ -299,6 +314,9 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
     PQ2_HIP(ctx, hipMemcpyAsync(ctx->d_meta.ptr, ctx->h_meta, meta_bytes, hipMemcpyHostToDevice, stream));
     PQ2_HIP(ctx, hipEventRecord(ctx->meta_copied, stream));
     ctx->meta_in_flight = true;
+    if (front)  // the streams' addresses, lengths and index widths come out of the page buffers on the device
+        PQ2_HIP(ctx, pq2_launch_front(ctx->d_meta.ptr, front->d_raw, front->n_pages, front->d_front_status, stream));
+    max_bits = std::max(max_bits, min_max_bits);
 
     const PageDev *d_pages = static_cast<const PageDev *>(ctx->d_meta.ptr);
     uint32_t *d_tile_page = static_cast<uint32_t *>(ctx->d_tile_page.ptr);
@@ -743,6 +761,85 @@ int32_t pq2_decode_selected_batch_device(pq2_ctx *ctx, const void *d_in, uint64_
         PQ2_HIP(ctx, pq2_launch_select(ctx->d_gather.ptr, static_cast<uint32_t>(pieces.size()), stream));
     }
     if (status) return fetch_status(ctx, status, n_pages);
+    return PQ2_OK;
+}
+
+int32_t pq2_decode_raw_pages_v1_device(pq2_ctx *ctx, const void *d_buf, uint64_t buf_bytes, const pq2_raw_page *pages,
+                                       uint64_t n_pages, uint32_t max_index_bits, uint32_t *d_rep, uint32_t *d_def,
+                                       uint32_t *d_idx, uint64_t out_values, int32_t *status, void *stream_) {
+    if (!ctx) return PQ2_INVALID_PARAMETER;
+    PQ2_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (n_pages > 0x2aaaaaaaull) return fail(ctx, PQ2_INVALID_PARAMETER, "too many pages in one batch");
+    if (n_pages > 0 && !pages) return fail(ctx, PQ2_INVALID_PARAMETER, "pages is NULL");
+    if (max_index_bits == 0 || max_index_bits > 32) max_index_bits = 32;
+    uint32_t *const outs[3] = {d_rep, d_def, d_idx};
+    for (uint32_t *o : outs)
+        if ((reinterpret_cast<uintptr_t>(o) & 3u) != 0) return fail(ctx, PQ2_INVALID_PARAMETER, "an output is misaligned");
+    // three streams per page; until front_kernel has run they span the whole page buffer (an upper bound of
+    // every stream's length, which sizes the header-position list) and the indices have the largest width
+    std::vector<pq2_page_desc> streams(3 * n_pages);
+    std::vector<RawPageDev> raw(n_pages);
+    for (uint64_t i = 0; i < n_pages; ++i) {
+        const pq2_raw_page &p = pages[i];
+        if (p.buf_off > buf_bytes || p.buf_len > buf_bytes - p.buf_off)
+            return fail(ctx, PQ2_INVALID_PARAMETER, "page buffer outside the buffer");
+        if (p.out_off > out_values || p.num_values > out_values - p.out_off)
+            return fail(ctx, PQ2_INVALID_PARAMETER, "page output outside the output buffers");
+        const bool has[3] = {p.max_rep_level > 0, p.max_def_level > 0, (p.flags & PQ2_RAW_DICT_INDICES) != 0};
+        const uint32_t bits[3] = {pq2_get_bit_width(static_cast<int16_t>(p.max_rep_level)),
+                                  pq2_get_bit_width(static_cast<int16_t>(p.max_def_level)), max_index_bits};
+        for (int k = 0; k < 3; ++k) {
+            if (has[k] && p.num_values > 0 && !outs[k]) return fail(ctx, PQ2_INVALID_PARAMETER, "an output that pages need is NULL");
+            pq2_page_desc &d = streams[3 * i + k];
+            d.in_off = p.buf_off;
+            d.in_len = p.buf_len;
+            d.num_bits = bits[k];
+            d.num_values = has[k] ? p.num_values : 0;
+            // absolute: enqueue_batch is given a null base
+            d.out_off = (reinterpret_cast<uintptr_t>(outs[k]) >> 2) + p.out_off;
+        }
+        raw[i].buf_addr = reinterpret_cast<uint64_t>(d_buf) + p.buf_off;
+        raw[i].buf_len = p.buf_len;
+        raw[i].what = (has[0] ? 1u : 0u) | (has[1] ? 2u : 0u) | (has[2] ? 4u : 0u) | (max_index_bits << 8);
+    }
+    int32_t st;
+    if (ctx->busy && ctx->last_stream != stream) PQ2_HIP(ctx, hipStreamSynchronize(ctx->last_stream));
+    const size_t raw_bytes = n_pages * sizeof(RawPageDev), all_bytes = raw_bytes + n_pages * sizeof(int32_t);
+    FrontJob job{nullptr, static_cast<uint32_t>(n_pages), nullptr};
+    if (n_pages > 0) {
+        if (ctx->gather_in_flight) {
+            PQ2_HIP(ctx, hipEventSynchronize(ctx->gather_copied));
+            ctx->gather_in_flight = false;
+        }
+        if (raw_bytes > ctx->h_gather_cap) {
+            if (ctx->h_gather) PQ2_HIP(ctx, hipHostFree(ctx->h_gather));
+            ctx->h_gather = nullptr;
+            ctx->h_gather_cap = 0;
+            const size_t cap = (raw_bytes + 4095) & ~size_t(4095);
+            PQ2_HIP(ctx, hipHostMalloc(&ctx->h_gather, cap, hipHostMallocDefault));
+            ctx->h_gather_cap = cap;
+        }
+        if (!ctx->gather_copied) PQ2_HIP(ctx, hipEventCreateWithFlags(&ctx->gather_copied, hipEventDisableTiming));
+        if ((st = reserve(ctx, ctx->d_gather, all_bytes))) return st;
+        std::memcpy(ctx->h_gather, raw.data(), raw_bytes);
+        PQ2_HIP(ctx, hipMemcpyAsync(ctx->d_gather.ptr, ctx->h_gather, raw_bytes, hipMemcpyHostToDevice, stream));
+        PQ2_HIP(ctx, hipEventRecord(ctx->gather_copied, stream));
+        ctx->gather_in_flight = true;
+        job.d_raw = ctx->d_gather.ptr;
+        job.d_front_status = reinterpret_cast<int32_t *>(static_cast<char *>(ctx->d_gather.ptr) + raw_bytes);
+    }
+    if ((st = enqueue_batch(ctx, nullptr, ~0ull, streams.data(), 3 * n_pages, nullptr, ~0ull >> 3, stream,
+                            n_pages ? &job : nullptr, max_index_bits)))
+        return st;
+    if (!status || n_pages == 0) return PQ2_OK;
+    std::vector<int32_t> of_streams(3 * n_pages), of_front(n_pages);
+    if ((st = fetch_status(ctx, of_streams.data(), 3 * n_pages))) return st;  // waits for the batch
+    PQ2_HIP(ctx, hipMemcpy(of_front.data(), job.d_front_status, n_pages * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < n_pages; ++i) {
+        status[i] = of_front[i];
+        for (int k = 0; k < 3 && status[i] == PQ2_OK; ++k) status[i] = of_streams[3 * i + k];
+    }
     return PQ2_OK;
 }
 

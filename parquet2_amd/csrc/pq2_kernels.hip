@@ -1227,6 +1227,71 @@ __global__ __launch_bounds__(256) void select_kernel(const SelectPiece *__restri
 }
 
 // ---------------------------------------------------------------------------
+// front_kernel: split_buffer_v1 (src/page/mod.rs:350-398) and the width byte of
+// dictionary indices (src/deserialize/utils.rs:13-27) for page buffers that lie
+// in device memory.  The host has built three stream descriptors per page
+// (repetition levels, definition levels, indices) that span the whole page
+// buffer; one thread per page reads the length prefixes and writes the streams'
+// real address, length and, for the indices, bit width into them before the
+// decode kernels read them.  A page that fails keeps its three streams empty
+// (they decode to zeros) and gets its status here.
+// ---------------------------------------------------------------------------
+struct RawPageDev {  // must match the host's
+    uint64_t buf_addr;
+    uint32_t buf_len;
+    uint32_t what;  // bit 0: repetition levels, bit 1: definition levels, bit 2: dictionary indices; bits 8..15: the
+                    // largest index width the batch was set up for
+};
+
+__global__ __launch_bounds__(256) void front_kernel(PageDev *__restrict__ streams, const RawPageDev *__restrict__ raw,
+                                                    uint32_t n_pages, int32_t *__restrict__ front_status) {
+    const uint32_t page = blockIdx.x * 256u + threadIdx.x;
+    if (page >= n_pages) return;
+    const RawPageDev rp = raw[page];
+    const uint8_t *const buf = (const uint8_t *)rp.buf_addr;
+    PageDev *const st = streams + 3u * (size_t)page;
+    uint32_t cursor = 0;
+    int32_t code = 0;
+    uint64_t addr[3] = {0, 0, 0};
+    uint32_t len[3] = {0, 0, 0};
+    uint32_t width = st[2].num_bits;
+    for (uint32_t level = 0; level < 2u && code == 0; ++level) {
+        if (((rp.what >> level) & 1u) == 0u) continue;
+        if (rp.buf_len - cursor < 4u) {  // get_length: None (src/encoding/mod.rs:14-21)
+            code = 1;
+            break;
+        }
+        const uint32_t l = (uint32_t)buf[cursor] | ((uint32_t)buf[cursor + 1u] << 8) | ((uint32_t)buf[cursor + 2u] << 16) |
+                           ((uint32_t)buf[cursor + 3u] << 24);
+        if (l > rp.buf_len - cursor - 4u) {  // buffer.get(4..4 + length): None
+            code = 1;
+            break;
+        }
+        addr[level] = rp.buf_addr + cursor + 4u;
+        len[level] = l;
+        cursor += 4u + l;
+    }
+    if (code == 0 && (rp.what & 4u) != 0u) {
+        if (rp.buf_len == cursor) {
+            code = 5;  // indices_buffer[0] on an empty buffer
+        } else {
+            width = buf[cursor];
+            if (width > 32u) code = 1;
+            else if (width > ((rp.what >> 8) & 0xffu)) code = 2;
+            addr[2] = rp.buf_addr + cursor + 1u;
+            len[2] = rp.buf_len - cursor - 1u;
+        }
+    }
+    front_status[page] = code;
+#pragma unroll
+    for (uint32_t k = 0; k < 3u; ++k) {
+        st[k].in_addr = code == 0 ? addr[k] : 0ull;
+        st[k].in_len = code == 0 ? len[k] : 0u;
+    }
+    if (code == 0) st[2].num_bits = width;
+}
+
+// ---------------------------------------------------------------------------
 // bitunpack64_kernel: `length` values of width w (1..64) from a bit-packed
 // buffer into u64 (bitpacked::Decoder<u64>, decode.rs:28-86; unpack64,
 // unpack.rs:21-95: LSB-first fields of a little-endian byte stream).  One value
@@ -1334,6 +1399,14 @@ extern "C" hipError_t pq2_launch_optional(const void *pages, uint32_t n_pages, u
 extern "C" hipError_t pq2_launch_select(const void *pieces, uint32_t n_pieces, hipStream_t stream) {
     if (n_pieces == 0) return hipSuccess;
     hipLaunchKernelGGL(pq2::select_kernel, dim3(n_pieces), dim3(256), 0, stream, (const pq2::SelectPiece *)pieces);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t pq2_launch_front(void *streams, const void *raw, uint32_t n_pages, int32_t *front_status,
+                                       hipStream_t stream) {
+    if (n_pages == 0) return hipSuccess;
+    hipLaunchKernelGGL(pq2::front_kernel, dim3((n_pages + 255u) / 256u), dim3(256), 0, stream, (pq2::PageDev *)streams,
+                       (const pq2::RawPageDev *)raw, n_pages, front_status);
     return hipGetLastError();
 }
 

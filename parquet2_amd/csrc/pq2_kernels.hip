@@ -712,7 +712,7 @@ template <int W, bool kCoh>
 __device__ __forceinline__ void expand_tile(const __amdgpu_buffer_rsrc_t rsrc, Window &win, uint2 *tbl,
                                             uint32_t *cidx, const u32x4 rs4, const uint32_t *__restrict__ hdrs,
                                             const uint32_t end, const uint32_t n, const uint32_t tile_first,
-                                            out_u32 *out, const uint32_t lane) {
+                                            out_u32 *out, const uint32_t lane, const uint32_t next_from = kEndPos) {
     constexpr uint32_t w = (uint32_t)W;
     constexpr uint32_t kSpans = kBlocksPerTile / kSpanBlocks;  // spans per tile
     const uint32_t spans = min(kSpans, (n - tile_first + kSpanValues - 1u) / kSpanValues);
@@ -757,7 +757,11 @@ __device__ __forceinline__ void expand_tile(const __amdgpu_buffer_rsrc_t rsrc, W
     }
     if (tile_from != kEndPos) {
         const uint32_t values = min(kTileValues - first_needing * kSpanValues, n - (tile_first + first_needing * kSpanValues));
-        win.fill(rsrc, tile_from, ((values * w) >> 3) + (values >> 3) + 128u, lane);
+        // the estimate assumes bit-packed values throughout; where the next tile's bytes begin, if known, bounds
+        // it (this tile's last value lies in the group before that byte or in the one that holds it)
+        uint32_t bytes = ((values * w) >> 3) + (values >> 3) + 128u;
+        if (next_from != kEndPos && next_from >= tile_from) bytes = min(bytes, next_from - tile_from + w + 16u);
+        win.fill(rsrc, tile_from, bytes, lane);
     }
     for (uint32_t i = 0; i < spans; ++i) {
         uint32_t hpi = hp[0];
@@ -774,7 +778,8 @@ template <bool kCoh>
 __device__ __forceinline__ void expand_page_tile(const PageDev &pg, const u32x4 rs4, const uint32_t tile_first,
                                                  const uint32_t *__restrict__ run_pos, uint8_t *win_lds,
                                                  const uint32_t win_bytes, const uint32_t win_bit_mask, uint2 *tbl,
-                                                 uint32_t *cidx, const uint32_t lane) {
+                                                 uint32_t *cidx, const uint32_t lane,
+                                                 const uint32_t next_from = kEndPos) {
     const uint32_t n = pg.num_values;
     const uint32_t delta = (uint32_t)(pg.in_addr & 15u);
     const uint32_t end = delta + pg.in_len;
@@ -791,7 +796,8 @@ __device__ __forceinline__ void expand_page_tile(const PageDev &pg, const u32x4 
     switch (pg.num_bits) {
 #define PQ2_W(N)                                                                                               \
     case N:                                                                                                    \
-        expand_tile<N, kCoh>(rsrc, win, tbl, cidx, rs4, run_pos + pg.run_base, end, n, tile_first, out, lane); \
+        expand_tile<N, kCoh>(rsrc, win, tbl, cidx, rs4, run_pos + pg.run_base, end, n, tile_first, out, lane, \
+                             next_from);                                                                        \
         break;
 #ifdef PQ2_ONLY_W  // single-width build for reading the generated code
         PQ2_W(PQ2_ONLY_W)
@@ -937,25 +943,37 @@ __global__ __launch_bounds__(256, 4) void decode_kernel(const PageDev *__restric
     const uint32_t n_tiles = (n + kTileValues - 1u) / kTileValues;
     for (uint32_t t = e; t < n_tiles; t += kDecodeExpanders) {
         const uint32_t need = min((t + 1u) * kTileValues, n);
-        uint32_t polls = 0;
-        while (__hip_atomic_load(parsed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
+        uint32_t polls = 0, covered;
+        while ((covered = __hip_atomic_load(parsed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < need) {
             __builtin_amdgcn_s_sleep(4);
             if (++polls == kMaxPolls) {  // never seen; a wait that cannot end would hang the GPU
                 if (lane == 0) status[page] = 6;  // PQ2_DEVICE_ERROR
                 return;
             }
         }
+        // the next tile's first Resume entry rides along (lane kBlocksPerTile) once the walk has covered that
+        // tile's first value: it says where this tile's bytes end
+        const bool next_known = t + 1u < n_tiles && covered > need;
         // the tile's four Resume entries, one per lane, past the vector cache (the walk wrote them just now)
         const uint32_t *rs = (const uint32_t *)(resume + (size_t)(pg.round_base(0) + t) * kBlocksPerTile);
         u32x4 rs4 = {0u, 0u, 0u, 0u};
-        if (lane < kBlocksPerTile) {
+        if (lane < kBlocksPerTile + (next_known ? 1u : 0u)) {
             rs4.x = load_coherent(rs + 4u * lane);
             rs4.y = load_coherent(rs + 4u * lane + 1u);
             rs4.z = load_coherent(rs + 4u * lane + 2u);
             rs4.w = load_coherent(rs + 4u * lane + 3u);
         }
+        uint32_t next_from = kEndPos;
+        if (next_known) {
+            const uint32_t rem_kind = __builtin_amdgcn_readlane(rs4.y, kBlocksPerTile);
+            const uint32_t payload = __builtin_amdgcn_readlane(rs4.z, kBlocksPerTile);
+            const uint32_t skip = __builtin_amdgcn_readlane(rs4.w, kBlocksPerTile);
+            // bit-packed: the group that holds the next tile's first value; RLE: the byte behind that run
+            next_from = (rem_kind >> 31) == kBitpacked ? payload + (skip >> 3) * pg.num_bits : skip;
+        }
+        if (lane >= kBlocksPerTile) rs4 = u32x4{0u, 0u, 0u, 0u};
         expand_page_tile<true>(pg, rs4, t * kTileValues, run_pos, lds + kWin + e * win_bytes, win_bytes, win_bit_mask,
-                               tbl, cidx, lane);
+                               tbl, cidx, lane, next_from);
         // (no release: the walk only counts tiles with this, and a wider fence would wait for the stores to drain)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         if (lane == 0)

@@ -203,6 +203,33 @@ int32_t reserve_pinned(pq2_ctx *ctx, size_t bytes) {
     return PQ2_OK;
 }
 
+// The small per-batch descriptor arrays of the entry points that add a kernel behind the decode (gather, nullable
+// pages, selected rows, raw pages) go through one page-locked block and one device block of the context.
+// stage_block: the page-locked block, at least `bytes` large and no longer read by an earlier upload.
+int32_t stage_block(pq2_ctx *ctx, size_t bytes, size_t device_bytes) {
+    if (ctx->gather_in_flight) {  // the previous batch's upload still reads the page-locked block
+        PQ2_HIP(ctx, hipEventSynchronize(ctx->gather_copied));
+        ctx->gather_in_flight = false;
+    }
+    if (bytes > ctx->h_gather_cap) {
+        if (ctx->h_gather) PQ2_HIP(ctx, hipHostFree(ctx->h_gather));
+        ctx->h_gather = nullptr;
+        ctx->h_gather_cap = 0;
+        const size_t cap = (std::max(bytes, ctx->h_gather_cap * 2) + 4095) & ~size_t(4095);
+        PQ2_HIP(ctx, hipHostMalloc(&ctx->h_gather, cap, hipHostMallocDefault));
+        ctx->h_gather_cap = cap;
+    }
+    if (!ctx->gather_copied) PQ2_HIP(ctx, hipEventCreateWithFlags(&ctx->gather_copied, hipEventDisableTiming));
+    return reserve(ctx, ctx->d_gather, std::max(bytes, device_bytes));
+}
+// upload_block: the first `bytes` of the page-locked block to the device block, on `stream`.
+int32_t upload_block(pq2_ctx *ctx, size_t bytes, hipStream_t stream) {
+    PQ2_HIP(ctx, hipMemcpyAsync(ctx->d_gather.ptr, ctx->h_gather, bytes, hipMemcpyHostToDevice, stream));
+    PQ2_HIP(ctx, hipEventRecord(ctx->gather_copied, stream));
+    ctx->gather_in_flight = true;
+    return PQ2_OK;
+}
+
 // Validates the batch, builds the device descriptors in pinned memory, uploads
 // them and enqueues parse + expand on `stream`.
 int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const pq2_page_desc *descs, uint64_t n_pages,
@@ -558,20 +585,7 @@ int32_t pq2_decode_dict_batch_device(pq2_ctx *ctx, const void *d_in, uint64_t in
     if ((st = enqueue_batch(ctx, d_in, in_bytes, descs, n_pages, d_idx, out_values, stream))) return st;
     if (n_pages > 0) {
         const size_t bytes = n_pages * sizeof(GatherPage);
-        if (ctx->gather_in_flight) {  // the previous batch's upload still reads the page-locked block
-            PQ2_HIP(ctx, hipEventSynchronize(ctx->gather_copied));
-            ctx->gather_in_flight = false;
-        }
-        if (bytes > ctx->h_gather_cap) {
-            if (ctx->h_gather) PQ2_HIP(ctx, hipHostFree(ctx->h_gather));
-            ctx->h_gather = nullptr;
-            ctx->h_gather_cap = 0;
-            const size_t cap = (std::max(bytes, ctx->h_gather_cap * 2) + 4095) & ~size_t(4095);
-            PQ2_HIP(ctx, hipHostMalloc(&ctx->h_gather, cap, hipHostMallocDefault));
-            ctx->h_gather_cap = cap;
-        }
-        if (!ctx->gather_copied) PQ2_HIP(ctx, hipEventCreateWithFlags(&ctx->gather_copied, hipEventDisableTiming));
-        if ((st = reserve(ctx, ctx->d_gather, bytes))) return st;
+        if ((st = stage_block(ctx, bytes, bytes))) return st;
         GatherPage *g = static_cast<GatherPage *>(ctx->h_gather);
         uint64_t tiles = 0, max_dict_bytes = 0;
         const uint64_t kGatherTileValues = pq2_gather_tile_values();
@@ -587,9 +601,7 @@ int32_t pq2_decode_dict_batch_device(pq2_ctx *ctx, const void *d_in, uint64_t in
             g[i].reserved = 0;
             tiles += (uint64_t(g[i].num_values) + kGatherTileValues - 1) / kGatherTileValues;
         }
-        PQ2_HIP(ctx, hipMemcpyAsync(ctx->d_gather.ptr, ctx->h_gather, bytes, hipMemcpyHostToDevice, stream));
-        PQ2_HIP(ctx, hipEventRecord(ctx->gather_copied, stream));
-        ctx->gather_in_flight = true;
+        if ((st = upload_block(ctx, bytes, stream))) return st;
         PQ2_HIP(ctx, pq2_launch_gather(ctx->d_gather.ptr, static_cast<uint32_t>(n_pages), static_cast<uint32_t>(tiles),
                                        value_size / 4, max_dict_bytes, static_cast<int32_t *>(ctx->d_status.ptr),
                                        stream));
@@ -640,20 +652,7 @@ int32_t pq2_decode_optional_dict_batch_device(pq2_ctx *ctx, const void *d_in, ui
     if ((st = enqueue_batch(ctx, d_in, in_bytes, both.data(), 2 * n_pages, d_scratch, at, stream))) return st;
     if (n_pages > 0) {
         const size_t bytes = n_pages * sizeof(OptionalPage);
-        if (ctx->gather_in_flight) {
-            PQ2_HIP(ctx, hipEventSynchronize(ctx->gather_copied));
-            ctx->gather_in_flight = false;
-        }
-        if (bytes > ctx->h_gather_cap) {
-            if (ctx->h_gather) PQ2_HIP(ctx, hipHostFree(ctx->h_gather));
-            ctx->h_gather = nullptr;
-            ctx->h_gather_cap = 0;
-            const size_t cap = (bytes + 4095) & ~size_t(4095);
-            PQ2_HIP(ctx, hipHostMalloc(&ctx->h_gather, cap, hipHostMallocDefault));
-            ctx->h_gather_cap = cap;
-        }
-        if (!ctx->gather_copied) PQ2_HIP(ctx, hipEventCreateWithFlags(&ctx->gather_copied, hipEventDisableTiming));
-        if ((st = reserve(ctx, ctx->d_gather, bytes))) return st;
+        if ((st = stage_block(ctx, bytes, bytes))) return st;
         OptionalPage *g = static_cast<OptionalPage *>(ctx->h_gather);
         for (uint64_t i = 0; i < n_pages; ++i) {
             const bool skip = ctx->host_status[i] != PQ2_OK || ctx->host_status[n_pages + i] != PQ2_OK;
@@ -669,9 +668,7 @@ int32_t pq2_decode_optional_dict_batch_device(pq2_ctx *ctx, const void *d_in, ui
             g[i].idx_status_at = static_cast<uint32_t>(n_pages + i);
             g[i].reserved = 0;
         }
-        PQ2_HIP(ctx, hipMemcpyAsync(ctx->d_gather.ptr, ctx->h_gather, bytes, hipMemcpyHostToDevice, stream));
-        PQ2_HIP(ctx, hipEventRecord(ctx->gather_copied, stream));
-        ctx->gather_in_flight = true;
+        if ((st = upload_block(ctx, bytes, stream))) return st;
         PQ2_HIP(ctx, pq2_launch_optional(ctx->d_gather.ptr, static_cast<uint32_t>(n_pages), value_size / 4,
                                          static_cast<int32_t *>(ctx->d_status.ptr), stream));
         // from here on the batch has n_pages statuses: a page's own, or else its index stream's
@@ -740,24 +737,9 @@ int32_t pq2_decode_selected_batch_device(pq2_ctx *ctx, const void *d_in, uint64_
     if (pieces.size() > 0x7fffffffull) return fail(ctx, PQ2_INVALID_PARAMETER, "too many intervals in one batch");
     if (!pieces.empty()) {
         const size_t bytes = pieces.size() * sizeof(SelectPiece);
-        if (ctx->gather_in_flight) {
-            PQ2_HIP(ctx, hipEventSynchronize(ctx->gather_copied));
-            ctx->gather_in_flight = false;
-        }
-        if (bytes > ctx->h_gather_cap) {
-            if (ctx->h_gather) PQ2_HIP(ctx, hipHostFree(ctx->h_gather));
-            ctx->h_gather = nullptr;
-            ctx->h_gather_cap = 0;
-            const size_t cap = (bytes + 4095) & ~size_t(4095);
-            PQ2_HIP(ctx, hipHostMalloc(&ctx->h_gather, cap, hipHostMallocDefault));
-            ctx->h_gather_cap = cap;
-        }
-        if (!ctx->gather_copied) PQ2_HIP(ctx, hipEventCreateWithFlags(&ctx->gather_copied, hipEventDisableTiming));
-        if ((st = reserve(ctx, ctx->d_gather, bytes))) return st;
+        if ((st = stage_block(ctx, bytes, bytes))) return st;
         std::memcpy(ctx->h_gather, pieces.data(), bytes);
-        PQ2_HIP(ctx, hipMemcpyAsync(ctx->d_gather.ptr, ctx->h_gather, bytes, hipMemcpyHostToDevice, stream));
-        PQ2_HIP(ctx, hipEventRecord(ctx->gather_copied, stream));
-        ctx->gather_in_flight = true;
+        if ((st = upload_block(ctx, bytes, stream))) return st;
         PQ2_HIP(ctx, pq2_launch_select(ctx->d_gather.ptr, static_cast<uint32_t>(pieces.size()), stream));
     }
     if (status) return fetch_status(ctx, status, n_pages);
@@ -808,24 +790,9 @@ int32_t pq2_decode_raw_pages_v1_device(pq2_ctx *ctx, const void *d_buf, uint64_t
     const size_t raw_bytes = n_pages * sizeof(RawPageDev), all_bytes = raw_bytes + n_pages * sizeof(int32_t);
     FrontJob job{nullptr, static_cast<uint32_t>(n_pages), nullptr};
     if (n_pages > 0) {
-        if (ctx->gather_in_flight) {
-            PQ2_HIP(ctx, hipEventSynchronize(ctx->gather_copied));
-            ctx->gather_in_flight = false;
-        }
-        if (raw_bytes > ctx->h_gather_cap) {
-            if (ctx->h_gather) PQ2_HIP(ctx, hipHostFree(ctx->h_gather));
-            ctx->h_gather = nullptr;
-            ctx->h_gather_cap = 0;
-            const size_t cap = (raw_bytes + 4095) & ~size_t(4095);
-            PQ2_HIP(ctx, hipHostMalloc(&ctx->h_gather, cap, hipHostMallocDefault));
-            ctx->h_gather_cap = cap;
-        }
-        if (!ctx->gather_copied) PQ2_HIP(ctx, hipEventCreateWithFlags(&ctx->gather_copied, hipEventDisableTiming));
-        if ((st = reserve(ctx, ctx->d_gather, all_bytes))) return st;
+        if ((st = stage_block(ctx, raw_bytes, all_bytes))) return st;
         std::memcpy(ctx->h_gather, raw.data(), raw_bytes);
-        PQ2_HIP(ctx, hipMemcpyAsync(ctx->d_gather.ptr, ctx->h_gather, raw_bytes, hipMemcpyHostToDevice, stream));
-        PQ2_HIP(ctx, hipEventRecord(ctx->gather_copied, stream));
-        ctx->gather_in_flight = true;
+        if ((st = upload_block(ctx, raw_bytes, stream))) return st;
         job.d_raw = ctx->d_gather.ptr;
         job.d_front_status = reinterpret_cast<int32_t *>(static_cast<char *>(ctx->d_gather.ptr) + raw_bytes);
     }

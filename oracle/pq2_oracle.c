@@ -908,3 +908,153 @@ double pq2o_time_bitunpack_u32(const uint8_t *packed, size_t packed_len, size_t 
     }
     return now_s() - t0;
 }
+
+/* ---- zigzag_leb128 and delta_bitpacked ------------------------------------------------------------------ */
+
+/* src/encoding/zigzag_leb128.rs:5-8 */
+int32_t pq2o_zigzag_leb128_decode(const uint8_t *values, size_t len, int64_t *value, size_t *consumed) {
+    uint64_t u;
+    int32_t st = pq2o_uleb128_decode(values, len, &u, consumed);
+    if (st != PQ2O_OK) return st;
+    *value = (int64_t)(u >> 1) ^ -(int64_t)(u & 1);
+    return PQ2O_OK;
+}
+
+/* delta_bitpacked::Block (decoder.rs:9-118) */
+typedef struct {
+    int64_t min_delta;
+    size_t values_per_mini_block;
+    const uint8_t *bitwidths, *bitwidths_end; /* std::slice::Iter<u8> */
+    const uint8_t *values;
+    size_t values_len;
+    size_t remaining;
+    size_t current_index;
+    int has_miniblock; /* Option<bitpacked::Decoder<u64>> */
+    pq2o_bitpacked_u64 miniblock;
+    size_t consumed_bytes;
+} delta_block;
+
+/* Block::advance_miniblock, decoder.rs:66-91 */
+static int32_t delta_advance_miniblock(delta_block *b) {
+    if (b->bitwidths == b->bitwidths_end) return PQ2O_REFERENCE_WOULD_PANIC; /* .next().unwrap() */
+    size_t num_bits = *b->bitwidths++;
+    if (num_bits > 0) {
+        size_t length = b->remaining < b->values_per_mini_block ? b->remaining : b->values_per_mini_block;
+        size_t miniblock_length = (b->values_per_mini_block * num_bits + 7) / 8; /* ceil8 */
+        if (miniblock_length > b->values_len) return PQ2O_OUT_OF_SPEC;
+        const uint8_t *miniblock = b->values;
+        b->values += miniblock_length;
+        b->values_len -= miniblock_length;
+        b->consumed_bytes += miniblock_length;
+        /* bitpacked::Decoder::try_new(miniblock, num_bits, length).unwrap(): unpack64 has no width above 64 */
+        int32_t st = pq2o_bitpacked_u64_try_new(&b->miniblock, miniblock, miniblock_length, num_bits, length);
+        if (st != PQ2O_OK) return PQ2O_REFERENCE_WOULD_PANIC;
+        b->has_miniblock = 1;
+    } else {
+        b->has_miniblock = 0;
+    }
+    b->current_index = 0;
+    return PQ2O_OK;
+}
+
+/* Block::try_new, decoder.rs:26-64 */
+static int32_t delta_block_try_new(delta_block *b, const uint8_t *values, size_t len, size_t num_mini_blocks,
+                                   size_t values_per_mini_block, size_t length) {
+    size_t most = num_mini_blocks * values_per_mini_block;
+    if (length > most) length = most;
+    size_t consumed;
+    int32_t st = pq2o_zigzag_leb128_decode(values, len, &b->min_delta, &consumed);
+    if (st != PQ2O_OK) return st;
+    b->consumed_bytes = consumed;
+    values += consumed;
+    len -= consumed;
+    if (num_mini_blocks > len) return PQ2O_OUT_OF_SPEC;
+    b->bitwidths = values;
+    b->bitwidths_end = values + num_mini_blocks;
+    b->consumed_bytes += num_mini_blocks;
+    b->values = values + num_mini_blocks;
+    b->values_len = len - num_mini_blocks;
+    b->values_per_mini_block = values_per_mini_block;
+    b->remaining = length;
+    b->current_index = 0;
+    b->has_miniblock = 0;
+    return delta_advance_miniblock(b);
+}
+
+/* Iterator for Block, decoder.rs:93-118: 1 = a value, 0 = None, negative = -(error status) */
+static int delta_block_next(delta_block *b, int64_t *out) {
+    if (b->remaining == 0) return 0;
+    uint64_t v = 0;
+    if (b->has_miniblock) {
+        if (!pq2o_bitpacked_u64_next(&b->miniblock, &v)) v = 0; /* unwrap_or_default */
+    }
+    *out = (int64_t)((uint64_t)b->min_delta + v);
+    b->current_index += 1;
+    b->remaining -= 1;
+    if (b->remaining > 0 && b->current_index == b->values_per_mini_block) {
+        int32_t st = delta_advance_miniblock(b);
+        if (st != PQ2O_OK) return -st; /* Some(Err(e)): the value is lost */
+    }
+    return 1;
+}
+
+int32_t pq2o_delta_bitpacked_decode(const uint8_t *values, size_t len, int64_t *out, size_t cap, size_t *n_values,
+                                    size_t *consumed_bytes) {
+    /* Decoder::try_new, decoder.rs:136-180 */
+    size_t consumed_total = 0, consumed;
+    uint64_t block_size, num_mini_blocks, total_count;
+    int64_t first_value;
+    int32_t st;
+    if ((st = pq2o_uleb128_decode(values, len, &block_size, &consumed)) != PQ2O_OK) return st;
+    consumed_total += consumed;
+    if (block_size % 128 != 0) return PQ2O_REFERENCE_WOULD_PANIC; /* assert_eq! */
+    values += consumed, len -= consumed;
+    if ((st = pq2o_uleb128_decode(values, len, &num_mini_blocks, &consumed)) != PQ2O_OK) return st;
+    consumed_total += consumed;
+    values += consumed, len -= consumed;
+    if ((st = pq2o_uleb128_decode(values, len, &total_count, &consumed)) != PQ2O_OK) return st;
+    consumed_total += consumed;
+    values += consumed, len -= consumed;
+    if ((st = pq2o_zigzag_leb128_decode(values, len, &first_value, &consumed)) != PQ2O_OK) return st;
+    consumed_total += consumed;
+    values += consumed, len -= consumed;
+    if (num_mini_blocks == 0) return PQ2O_REFERENCE_WOULD_PANIC; /* division by zero */
+    size_t values_per_mini_block = (size_t)(block_size / num_mini_blocks);
+    if (values_per_mini_block % 8 != 0) return PQ2O_REFERENCE_WOULD_PANIC; /* assert_eq! */
+    *n_values = (size_t)total_count;
+    if (total_count > cap) return PQ2O_INVALID_PARAMETER;
+
+    delta_block block;
+    int has_block = 0;
+    if (total_count > 1) {
+        st = delta_block_try_new(&block, values, len, (size_t)num_mini_blocks, values_per_mini_block,
+                                 (size_t)total_count - 1);
+        if (st != PQ2O_OK) return st;
+        has_block = 1;
+    }
+    /* Iterator for Decoder, decoder.rs:216-243 */
+    size_t values_remaining = (size_t)total_count, produced = 0;
+    int64_t next_value = first_value;
+    while (values_remaining != 0) {
+        out[produced++] = next_value;
+        values_remaining -= 1;
+        if (values_remaining == 0) break;
+        /* load_delta, decoder.rs:187-213 */
+        int64_t delta;
+        int r = delta_block_next(&block, &delta);
+        if (r < 0) return -r;
+        if (r == 0) {
+            values += block.consumed_bytes, len -= block.consumed_bytes;
+            consumed_total += block.consumed_bytes;
+            st = delta_block_try_new(&block, values, len, (size_t)num_mini_blocks, values_per_mini_block,
+                                     values_remaining);
+            if (st != PQ2O_OK) return st;
+            r = delta_block_next(&block, &delta);
+            if (r < 0) return -r;
+            if (r == 0) return PQ2O_OUT_OF_SPEC; /* "Missing block" */
+        }
+        next_value = (int64_t)((uint64_t)next_value + (uint64_t)delta);
+    }
+    *consumed_bytes = consumed_total + (has_block ? block.consumed_bytes : 0);
+    return PQ2O_OK;
+}

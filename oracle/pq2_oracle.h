@@ -206,6 +206,19 @@ int32_t pq2o_filtered_bitmap_runs(const pq2o_bitmap_run *runs, size_t n_runs, co
                                   const pq2o_interval *intervals, size_t n_intervals, pq2o_filtered_run *out,
                                   size_t cap, size_t *n_out);
 
+/* src/encoding/zigzag_leb128.rs:5-8 */
+int32_t pq2o_zigzag_leb128_decode(const uint8_t *values, size_t len, int64_t *value, size_t *consumed);
+
+/* delta_bitpacked::Decoder::try_new(values)?.collect::<Result<Vec<i64>>>() and consumed_bytes()
+ * (src/encoding/delta_bitpacked/decoder.rs:26-244).  Writes at most `cap` values, reports the header's
+ * total count in *n_values (PQ2O_INVALID_PARAMETER, with nothing else decided, if it exceeds cap).
+ * PQ2O_OUT_OF_SPEC where the reference returns Error::OutOfSpec (:40-44, :75-79),
+ * PQ2O_REFERENCE_WOULD_PANIC where it panics (the asserts :140, :156, a division by zero :155, slices
+ * beyond the data, a 10th varint byte above 1, a mini-block wider than 64 bits).  Sums wrap (the
+ * release build; the debug build panics on overflow, :235). */
+int32_t pq2o_delta_bitpacked_decode(const uint8_t *values, size_t len, int64_t *out, size_t cap, size_t *n_values,
+                                    size_t *consumed_bytes);
+
 /* Timing helpers for bench.py's cpu_baseline leg: decode `reps` times and
  * return elapsed seconds (CLOCK_MONOTONIC). */
 double pq2o_time_hybrid_rle_decode(const uint8_t *data, size_t len, uint32_t num_bits, size_t num_values,

@@ -88,6 +88,8 @@ class Oracle:
         lib.pq2o_bitpacked_encode_u32.argtypes = [u32p, sz, sz, u8p, sz]
         lib.pq2o_bitunpack_u32.argtypes = [u8p, sz, sz, sz, u32p]
         lib.pq2o_bitunpack_u64.argtypes = [u8p, sz, sz, sz, u64p]
+        lib.pq2o_zigzag_leb128_decode.argtypes = [u8p, sz, C.POINTER(C.c_int64), C.POINTER(sz)]
+        lib.pq2o_delta_bitpacked_decode.argtypes = [u8p, sz, C.POINTER(C.c_int64), sz, C.POINTER(sz), C.POINTER(sz)]
         lib.pq2o_run_decoder_new.restype = None
         lib.pq2o_run_decoder_new.argtypes = [C.POINTER(RunDecoder), u8p, sz, sz]
         lib.pq2o_run_decoder_next.argtypes = [C.POINTER(RunDecoder), C.POINTER(HybridEncoded)]
@@ -168,6 +170,21 @@ class Oracle:
         out = np.zeros(length, dtype=np.uint64)
         st = self.lib.pq2o_bitunpack_u64(_ptr(a), a.size, num_bits, length, _ptr(out, u64p))
         return st, out
+
+    def zigzag_leb128_decode(self, data):
+        a = _as_u8(data)
+        v, c = C.c_int64(), C.c_size_t()
+        st = self.lib.pq2o_zigzag_leb128_decode(_ptr(a), a.size, C.byref(v), C.byref(c))
+        return st, v.value, c.value
+
+    def delta_bitpacked_decode(self, data, cap):
+        """(status, values int64 ndarray of the header's count, consumed bytes)"""
+        a = _as_u8(data)
+        out = np.zeros(max(cap, 1), dtype=np.int64)
+        n, c = C.c_size_t(), C.c_size_t()
+        st = self.lib.pq2o_delta_bitpacked_decode(_ptr(a), a.size, out.ctypes.data_as(C.POINTER(C.c_int64)), cap,
+                                                  C.byref(n), C.byref(c))
+        return st, out[:min(n.value, cap)], c.value
 
     # -- hybrid rle -------------------------------------------------------
     def runs(self, data, num_bits):

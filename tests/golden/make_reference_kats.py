@@ -197,6 +197,25 @@ def main():
          "expected": [[R, True, 1], [S, 7], [S, 0], [R, False, 2]]},
     ]
 
+    # ---- zigzag_leb128 and delta_bitpacked (the u64 unpack's caller) --------------------------------------
+    kats["zigzag_leb128_decode"] = {
+        "src": "src/encoding/zigzag_leb128.rs:23-43 test_decode",
+        "cases": [[0, 0], [1, -1], [2, 1], [3, -2], [4, 2], [5, -3], [6, 3], [7, -4], [8, 4], [9, -5]],
+    }
+    kats["delta_bitpacked_decode"] = [
+        {"src": "src/encoding/delta_bitpacked/decoder.rs:250-266 single_value",
+         "data": [128, 1, 4, 1, 2], "expected": [1], "consumed": 5},
+        {"src": "src/encoding/delta_bitpacked/decoder.rs:268-288 test_from_spec",
+         "data": [128, 1, 4, 5, 2, 2, 0, 0, 0, 0], "expected": [1, 2, 3, 4, 5], "consumed": 10},
+        {"src": "src/encoding/delta_bitpacked/decoder.rs:290-318 case2",
+         "data": [128, 1, 4, 6, 2, 7, 3, 0, 0, 0, 0b01101101, 0b00001011, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 2, 3],
+         "expected": [1, 2, 3, 4, 5, 1], "consumed": 22},
+        {"src": "src/encoding/delta_bitpacked/decoder.rs:320-364 multiple_miniblocks",
+         "data": [128, 1, 4, 65, 100, 7, 3, 4, 255, 0] + [0] * 12 + [0x88] * 16 + [1, 2, 3],
+         "expected": [50] + [46 - 4 * i for i in range(32)] + [-74 + 4 * i for i in range(32)],
+         "consumed": 38},
+    ]
+
     with open(OUT, "w") as f:
         json.dump(kats, f, indent=1)
         f.write("\n")

@@ -205,3 +205,11 @@ def test_split_buffer_and_dict_locate(oracle):
     assert oracle.dict_indices_locate(bytes([12, 3, 2])) == (OK, 12, 1)
     assert oracle.dict_indices_locate(bytes([33, 3, 2]))[0] == OUT_OF_SPEC
     assert oracle.dict_indices_locate(b"")[0] == REFERENCE_WOULD_PANIC
+
+
+def test_zigzag_and_delta_bitpacked(oracle, kats):
+    for byte, expected in kats["zigzag_leb128_decode"]["cases"]:
+        assert oracle.zigzag_leb128_decode(bytes([byte])) == (0, expected, 1)
+    for c in kats["delta_bitpacked_decode"]:
+        st, values, consumed = oracle.delta_bitpacked_decode(bytes(c["data"]), len(c["expected"]))
+        assert st == 0 and values.tolist() == c["expected"] and consumed == c["consumed"], c["src"]

@@ -262,6 +262,36 @@ int32_t pq2_bitunpack_u64_device(pq2_ctx *ctx, const void *d_packed, uint64_t pa
 int32_t pq2_bitunpack_u64_host(pq2_ctx *ctx, const void *packed, uint64_t packed_len, uint32_t num_bits,
                                uint64_t length, uint64_t *out);
 
+/* ---- DELTA_BINARY_PACKED --------------------------------------------------- */
+
+/* Replaces, for every stream i of the batch,
+ *   let mut d = delta_bitpacked::Decoder::try_new(&in[in_off..in_off+in_len])?;
+ *   let values = d.by_ref().collect::<Result<Vec<i64>, _>>()?;  let consumed = d.consumed_bytes();
+ * (src/encoding/delta_bitpacked/decoder.rs:121-244 over Block, :9-118; zigzag_leb128.rs:5-8;
+ * uleb128.rs:3-23; mini-blocks are bitpacked::Decoder<u64>, decoder.rs:85) with the streams and
+ * the values resident in HBM.  A descriptor's num_bits is ignored, its num_values is the room
+ * (in i64) at d_out[out_off..]; the header's total_count says how many values the stream holds
+ * and that many are written.  d_out 8-byte aligned.  The additions wrap as the reference's
+ * wrapping_add does (:109, :241).
+ *
+ * The call waits for completion.  Per stream: `status` (required), and if non-NULL `num_values`
+ * (total_count, also when it exceeds the room) and `consumed_bytes` (decoder.rs:182-185 after the
+ * last value: the bytes of the mini-blocks that were opened, not those of the unused tail of the
+ * last block).  Statuses: PQ2_OK; PQ2_OUT_OF_SPEC (a block without its bit widths, :46-50; a
+ * mini-block without its bytes, :73-77; "Missing block", :199-206); PQ2_REFERENCE_WOULD_PANIC
+ * (block_size not a multiple of 128, :141; zero mini-blocks, :158; values per mini-block not a
+ * multiple of 8, :159; a bit width above 64, :85; a varint that overflows, uleb128.rs:10-12);
+ * PQ2_INVALID_PARAMETER (total_count larger than the room).  The values of a stream with a
+ * non-OK status are unspecified. */
+int32_t pq2_delta_bitpacked_decode_batch_device(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes,
+                                                const pq2_page_desc *descs, uint64_t n_pages, int64_t *d_out,
+                                                uint64_t out_values, uint64_t *num_values, uint64_t *consumed_bytes,
+                                                int32_t *status, void *stream);
+/* One stream in host memory: what a per-page drop-in of delta_bitpacked::Decoder calls.  Returns
+ * the stream's status; `out` has room for `cap` values. */
+int32_t pq2_delta_bitpacked_decode_host(pq2_ctx *ctx, const void *values, uint64_t len, int64_t *out, uint64_t cap,
+                                        uint64_t *num_values, uint64_t *consumed_bytes);
+
 /* ---- multi-GPU sharding ---------------------------------------------------- */
 
 /* Splits a batch into `n_parts` contiguous page ranges balanced on output

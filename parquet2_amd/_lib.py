@@ -89,6 +89,11 @@ SIGNATURES = {
     "pq2_bitunpack_u64_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p,
                                               C.c_void_p]),
     "pq2_bitunpack_u64_host": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p]),
+    "pq2_delta_bitpacked_decode_batch_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+                                                             C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
+                                                             C.c_void_p, C.c_void_p]),
+    "pq2_delta_bitpacked_decode_host": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, u64p,
+                                                     u64p]),
     "pq2_partition_pages": (C.c_int32, [C.c_void_p, C.c_uint64, C.c_uint32, u64p]),
     "pq2_ceil8": (C.c_uint64, [C.c_uint64]),
     "pq2_get_length": (C.c_int32, [C.c_void_p, C.c_uint64, u64p]),
@@ -300,6 +305,30 @@ class Context:
     def bitunpack_u64_device(self, d_packed_ptr, packed_len, num_bits, length, d_out_ptr, stream=0):
         self._check(lib().pq2_bitunpack_u64_device(self._h, C.c_void_p(d_packed_ptr), packed_len, num_bits, length,
                                                    C.c_void_p(d_out_ptr), C.c_void_p(stream)))
+
+    # ---- DELTA_BINARY_PACKED -----------------------------------------------------
+    def delta_bitpacked_decode_batch_device(self, d_in_ptr, in_bytes, descs, d_out_ptr, out_values, stream=0):
+        """delta_bitpacked::Decoder over every stream of the batch (pq2_delta_bitpacked_decode_batch_device); a
+        descriptor's num_values is the room at its out_off, in int64.  Returns (statuses, num_values, consumed_bytes)."""
+        descs = np.ascontiguousarray(descs, dtype=PAGE_DESC_DTYPE)
+        status = np.zeros(len(descs), dtype=np.int32)
+        counts = np.zeros(len(descs), dtype=np.uint64)
+        consumed = np.zeros(len(descs), dtype=np.uint64)
+        st = lib().pq2_delta_bitpacked_decode_batch_device(self._h, C.c_void_p(d_in_ptr), in_bytes, ptr(descs),
+                                                           len(descs), C.c_void_p(d_out_ptr), out_values, ptr(counts),
+                                                           ptr(consumed), ptr(status), C.c_void_p(stream))
+        self._check(st)
+        return status, counts, consumed
+
+    def delta_bitpacked_decode_host(self, values, cap):
+        """One stream in host memory: (values as int64, consumed_bytes); raises as the reference's decoder errs."""
+        values = as_u8(values)
+        out = np.zeros(max(cap, 1), dtype=np.int64)
+        n, consumed = C.c_uint64(0), C.c_uint64(0)
+        st = lib().pq2_delta_bitpacked_decode_host(self._h, ptr(values), values.size, ptr(out), cap, C.byref(n),
+                                                   C.byref(consumed))
+        self._check(st)
+        return out[:n.value], consumed.value
 
     def bitunpack_u32_device(self, d_packed_ptr, packed_len, num_bits, length, d_out_ptr, stream=0):
         self._check(lib().pq2_bitunpack_u32_device(self._h, C.c_void_p(d_packed_ptr), packed_len, num_bits, length,

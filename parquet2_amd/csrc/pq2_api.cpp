@@ -40,6 +40,7 @@ hipError_t pq2_launch_optional(const void *pages, uint32_t n_pages, uint32_t val
                                hipStream_t stream);
 hipError_t pq2_launch_bitunpack64(const void *d_packed, uint32_t packed_len, uint32_t num_bits, uint32_t length,
                                   uint64_t *d_out, hipStream_t stream);
+hipError_t pq2_launch_delta(const void *pages, uint32_t n_pages, void *results, hipStream_t stream);
 }
 
 namespace {
@@ -93,6 +94,18 @@ struct RawPageDev {  // must match pq2::RawPageDev
     uint32_t buf_len, what;
 };
 static_assert(sizeof(RawPageDev) == 16, "RawPageDev layout");
+
+struct DeltaPage {  // must match pq2::DeltaPage
+    uint64_t in_addr, out_addr;
+    uint32_t in_len, cap;
+};
+static_assert(sizeof(DeltaPage) == 24, "DeltaPage layout");
+struct DeltaResult {  // must match pq2::DeltaResult
+    int32_t status;
+    uint32_t consumed;
+    uint64_t num_values;
+};
+static_assert(sizeof(DeltaResult) == 16, "DeltaResult layout");
 
 // What pq2_decode_raw_pages_v1_device adds to a batch: front_kernel patches the uploaded stream descriptors.
 struct FrontJob {
@@ -1046,6 +1059,78 @@ int32_t pq2_bitunpack_u64_host(pq2_ctx *ctx, const void *packed, uint64_t packed
                                         static_cast<uint32_t>(length), static_cast<uint64_t *>(ctx->d_out.ptr), s));
     PQ2_HIP(ctx, hipMemcpyAsync(out, ctx->d_out.ptr, length * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     PQ2_HIP(ctx, hipStreamSynchronize(s));
+    return PQ2_OK;
+}
+
+int32_t pq2_delta_bitpacked_decode_batch_device(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes,
+                                                const pq2_page_desc *descs, uint64_t n_pages, int64_t *d_out,
+                                                uint64_t out_values, uint64_t *num_values, uint64_t *consumed_bytes,
+                                                int32_t *status, void *stream_) {
+    if (!ctx) return PQ2_INVALID_PARAMETER;
+    PQ2_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (n_pages > 0x7fffffffull) return fail(ctx, PQ2_INVALID_PARAMETER, "too many streams in one batch");
+    if (n_pages > 0 && (!descs || !status)) return fail(ctx, PQ2_INVALID_PARAMETER, "descs or status is NULL");
+    if ((reinterpret_cast<uintptr_t>(d_out) & 7u) != 0) return fail(ctx, PQ2_INVALID_PARAMETER, "d_out misaligned");
+    for (uint64_t i = 0; i < n_pages; ++i) {
+        const pq2_page_desc &d = descs[i];
+        if (d.in_len > PQ2_MAX_PAGE_BYTES || d.in_off > in_bytes || d.in_len > in_bytes - d.in_off)
+            return fail(ctx, PQ2_INVALID_PARAMETER, "stream " + std::to_string(i) + " outside the input buffer");
+        if (d.num_values > PQ2_MAX_PAGE_VALUES || d.out_off > out_values || d.num_values > out_values - d.out_off)
+            return fail(ctx, PQ2_INVALID_PARAMETER, "stream " + std::to_string(i) + " outside the output buffer");
+    }
+    if (n_pages == 0) return PQ2_OK;
+    int32_t st;
+    if (ctx->busy && ctx->last_stream != stream) PQ2_HIP(ctx, hipStreamSynchronize(ctx->last_stream));
+    // one block: the descriptors, then the results
+    const size_t desc_bytes = (n_pages * sizeof(DeltaPage) + 15) & ~size_t(15);
+    const size_t all_bytes = desc_bytes + n_pages * sizeof(DeltaResult);
+    if ((st = stage_block(ctx, desc_bytes, all_bytes))) return st;
+    DeltaPage *h = static_cast<DeltaPage *>(ctx->h_gather);
+    for (uint64_t i = 0; i < n_pages; ++i) {
+        h[i].in_addr = reinterpret_cast<uint64_t>(static_cast<const uint8_t *>(d_in) + descs[i].in_off);
+        h[i].out_addr = reinterpret_cast<uint64_t>(d_out + descs[i].out_off);
+        h[i].in_len = descs[i].in_len;
+        h[i].cap = static_cast<uint32_t>(descs[i].num_values);
+    }
+    if ((st = upload_block(ctx, n_pages * sizeof(DeltaPage), stream))) return st;
+    uint8_t *d_results = static_cast<uint8_t *>(ctx->d_gather.ptr) + desc_bytes;
+    PQ2_HIP(ctx, pq2_launch_delta(ctx->d_gather.ptr, static_cast<uint32_t>(n_pages), d_results, stream));
+    std::vector<DeltaResult> results(n_pages);
+    PQ2_HIP(ctx, hipMemcpyAsync(results.data(), d_results, n_pages * sizeof(DeltaResult), hipMemcpyDeviceToHost,
+                                stream));
+    PQ2_HIP(ctx, hipStreamSynchronize(stream));
+    for (uint64_t i = 0; i < n_pages; ++i) {
+        status[i] = results[i].status;
+        if (num_values) num_values[i] = results[i].num_values;
+        if (consumed_bytes) consumed_bytes[i] = results[i].consumed;
+    }
+    return PQ2_OK;
+}
+
+int32_t pq2_delta_bitpacked_decode_host(pq2_ctx *ctx, const void *values, uint64_t len, int64_t *out, uint64_t cap,
+                                        uint64_t *num_values, uint64_t *consumed_bytes) {
+    if (!ctx) return PQ2_INVALID_PARAMETER;
+    PQ2_HIP(ctx, hipSetDevice(ctx->device));
+    if (len > PQ2_MAX_PAGE_BYTES || cap > PQ2_MAX_PAGE_VALUES)
+        return fail(ctx, PQ2_INVALID_PARAMETER, "buffer too large for one call");
+    int32_t st;
+    if ((st = reserve(ctx, ctx->d_in, len + 16))) return st;
+    if ((st = reserve(ctx, ctx->d_out, std::max<uint64_t>(cap, 1) * sizeof(int64_t)))) return st;
+    hipStream_t s = nullptr;
+    if (len) PQ2_HIP(ctx, hipMemcpyAsync(ctx->d_in.ptr, values, len, hipMemcpyHostToDevice, s));
+    pq2_page_desc d = {};
+    d.in_len = static_cast<uint32_t>(len);
+    d.num_values = cap;
+    int32_t page_status = PQ2_OK;
+    uint64_t n = 0;
+    if ((st = pq2_delta_bitpacked_decode_batch_device(ctx, ctx->d_in.ptr, len, &d, 1,
+                                                      static_cast<int64_t *>(ctx->d_out.ptr), cap, &n, consumed_bytes,
+                                                      &page_status, s)))
+        return st;
+    if (num_values) *num_values = n;
+    if (page_status != PQ2_OK) return fail(ctx, page_status, "delta_bitpacked::Decoder");
+    if (n) PQ2_HIP(ctx, hipMemcpy(out, ctx->d_out.ptr, n * sizeof(int64_t), hipMemcpyDeviceToHost));
     return PQ2_OK;
 }
 

@@ -1334,6 +1334,194 @@ __global__ __launch_bounds__(256) void bitunpack64_kernel(uint64_t in_addr, uint
     }
 }
 
+// ---------------------------------------------------------------------------
+// delta_kernel: DELTA_BINARY_PACKED streams into i64 (delta_bitpacked::Decoder,
+// src/encoding/delta_bitpacked/decoder.rs:121-244, over Block, :9-118,
+// zigzag_leb128.rs:5-8 and uleb128.rs:3-23).  One wave per stream.  The blocks
+// of a stream follow each other (where one begins is known only once the widths
+// of the one before are read), the inside of a block is lane-parallel: up to 64
+// mini-blocks have their widths read, their byte ranges summed and checked in
+// one step, then every lane takes one value of the block, adds the block's
+// minimum delta and a 64-bit wave prefix sum turns the deltas into values.
+// ---------------------------------------------------------------------------
+struct DeltaPage {
+    uint64_t in_addr;
+    uint64_t out_addr;  // int64 values
+    uint32_t in_len;
+    uint32_t cap;  // values the output holds
+};
+struct DeltaResult {
+    int32_t status;
+    uint32_t consumed;    // Decoder::consumed_bytes() once every value is taken (decoder.rs:182-185)
+    uint64_t num_values;  // total_count of the header
+};
+
+#define PQ2_DPP64(V, CTRL, ROWS)                                                                                \
+    (((uint64_t)(uint32_t)__builtin_amdgcn_update_dpp(0u, (uint32_t)((V) >> 32), CTRL, ROWS, 0xf, false) << 32) | \
+     (uint32_t)__builtin_amdgcn_update_dpp(0u, (uint32_t)(V), CTRL, ROWS, 0xf, false))
+// wave_inclusive_sum for 64-bit terms (the sums wrap, as the reference's wrapping adds do)
+__device__ __forceinline__ uint64_t wave_inclusive_sum64(uint64_t v) {
+    v += PQ2_DPP64(v, 0x111, 0xf);
+    v += PQ2_DPP64(v, 0x112, 0xf);
+    v += PQ2_DPP64(v, 0x114, 0xf);
+    v += PQ2_DPP64(v, 0x118, 0xf);
+    v += PQ2_DPP64(v, 0x142, 0xa);
+    v += PQ2_DPP64(v, 0x143, 0xc);
+    return v;
+}
+#undef PQ2_DPP64
+
+__device__ __forceinline__ uint64_t lane_value64(uint64_t v, uint32_t lane) {
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((uint32_t)(v >> 32), lane) << 32) |
+           (uint32_t)__builtin_amdgcn_readlane((uint32_t)v, lane);
+}
+
+struct Varint {
+    uint64_t value;
+    uint32_t used;
+    uint32_t panics;
+};
+// uleb128::decode (uleb128.rs:3-23) on a window that holds one stream byte per lane (bit 8 set: behind the
+// stream's end), from lane `o` on; o + 9 < 64.
+__device__ __forceinline__ Varint varint_at(uint32_t window, uint32_t o) {
+    Varint r = {0ull, 0u, 0u};
+    for (uint32_t i = 0; i < 10u; ++i) {
+        const uint32_t b = (uint32_t)__builtin_amdgcn_readlane(window, o + i);
+        if (b & 0x100u) break;
+        r.used += 1u;
+        if (i == 9u && (b & 0xffu) > 1u) {  // `shift == 63 && *byte > 1`
+            r.panics = 1u;
+            break;
+        }
+        r.value |= (uint64_t)(b & 0x7fu) << (7u * i);
+        if ((b & 0x80u) == 0u) break;
+    }
+    return r;
+}
+__device__ __forceinline__ uint64_t zigzag(uint64_t u) { return (u >> 1) ^ (0ull - (u & 1ull)); }
+
+// The decode of one stream by one wave; returns the status.  `tbl_start` / `tbl_bits`: 64 LDS words each.
+__device__ int32_t delta_decode(const DeltaPage pg, uint32_t lane, uint32_t *tbl_start, uint32_t *tbl_bits,
+                                uint64_t &num_values, uint32_t &consumed) {
+    const uint32_t delta = (uint32_t)(pg.in_addr & 15u);
+    const uint32_t end = delta + pg.in_len;
+    const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(pg.in_addr - delta, (end + 3u) & ~3u);
+    uint64_t *out = (uint64_t *)pg.out_addr;
+    auto byte_at = [&](uint32_t a) -> uint32_t {
+        return (__builtin_amdgcn_raw_buffer_load_b32(rsrc, a & ~3u, 0, 0) >> ((a & 3u) * 8u)) & 0xffu;
+    };
+    auto window_at = [&](uint32_t a) -> uint32_t { return a + lane < end ? byte_at(a + lane) : 0x100u; };
+
+    // Decoder::try_new, decoder.rs:136-180
+    uint32_t pos = delta;
+    uint32_t window = window_at(pos);
+    const Varint block_size = varint_at(window, 0u);
+    if (block_size.panics || (block_size.value & 127ull) != 0ull) return 5;  // assert_eq!(block_size % 128, 0)
+    uint32_t o = block_size.used;
+    const Varint num_mini_blocks = varint_at(window, o);
+    if (num_mini_blocks.panics) return 5;
+    o += num_mini_blocks.used;
+    const Varint total_count = varint_at(window, o);
+    if (total_count.panics) return 5;
+    o += total_count.used;
+    const Varint first = varint_at(window, o);
+    if (first.panics) return 5;
+    o += first.used;
+    if (num_mini_blocks.value == 0ull) return 5;  // block_size / num_mini_blocks
+    const uint64_t per_mini = block_size.value / num_mini_blocks.value;
+    if ((per_mini & 7ull) != 0ull) return 5;  // assert_eq!(values_per_mini_block % 8, 0)
+    num_values = total_count.value;
+    if (total_count.value > pg.cap) return 2;
+    pos += o;
+
+    uint64_t acc = zigzag(first.value);
+    if (total_count.value != 0ull && lane == 0u) out[0] = acc;
+    uint32_t remaining = total_count.value != 0ull ? (uint32_t)total_count.value - 1u : 0u;  // deltas still to take
+    uint32_t done = 0u, empties = 0u;
+    const uint64_t block_most = num_mini_blocks.value * per_mini;  // <= block_size
+    // value indices stay below 2^31: a mini-block that long holds the whole of any block
+    const uint32_t per_mini32 = per_mini > 0x80000000ull ? 0x80000000u : (uint32_t)per_mini;
+
+    while (remaining != 0u) {
+        // Block::try_new, decoder.rs:26-64
+        window = window_at(pos);
+        const Varint md = varint_at(window, 0u);
+        if (md.panics) return 5;
+        const uint64_t min_delta = zigzag(md.value);
+        const uint32_t widths_at = pos + md.used;
+        if (num_mini_blocks.value > (uint64_t)(end - widths_at)) return 1;  // "Block must contain at least..."
+        const uint32_t block_len = (uint64_t)remaining < block_most ? remaining : (uint32_t)block_most;
+        // the first mini-block is opened by try_new, each further one after the last value of the one before
+        const uint32_t needed = block_len == 0u ? 1u : (block_len - 1u) / per_mini32 + 1u;
+        uint32_t at = widths_at + (uint32_t)num_mini_blocks.value;  // where the next mini-block's bytes begin
+        for (uint32_t g = 0; g < needed; g += 64u) {
+            // Block::advance_miniblock, decoder.rs:66-91, for the mini-blocks g .. g + 63
+            const uint32_t j = g + lane;
+            const uint32_t bits = j < needed ? byte_at(widths_at + j) : 0u;
+            uint64_t length = bits != 0u ? (per_mini * bits + 7ull) / 8ull : 0ull;  // ceil8(values_per_mini_block * num_bits)
+            if (length > 0x100000000ull) length = 0x100000000ull;                   // more than any stream holds
+            const uint64_t upto = wave_inclusive_sum64(length);
+            const bool short_of = bits != 0u && upto > (uint64_t)(end - at);  // "block must contain at least miniblock_length bytes"
+            // bitpacked::Decoder::<u64>::try_new(..).unwrap() unpacks the first pack, unless there are no bytes at
+            // all (decode.rs:46-50), and unpack64 has no width above 64
+            const uint64_t bad = __ballot(short_of || (bits > 64u && length != 0ull));
+            if (bad != 0ull) return ((__ballot(short_of) >> __builtin_ctzll(bad)) & 1ull) != 0ull ? 1 : 5;
+            tbl_start[lane] = at + (uint32_t)(upto - length);
+            tbl_bits[lane] = bits;
+            wave_sync();
+            at += (uint32_t)lane_value64(upto, 63u);
+            // Iterator for Block (:93-118) and for Decoder (:216-243): the values of these mini-blocks
+            const uint64_t group_end = ((uint64_t)g + 64ull) * per_mini32;
+            const uint32_t v_end = group_end < block_len ? (uint32_t)group_end : block_len;
+            for (uint32_t base = g * per_mini32; base < v_end; base += 64u) {
+                const uint32_t v = base + lane;
+                uint64_t term = 0ull;
+                if (v < v_end) {
+                    const uint32_t mini = v / per_mini32;
+                    const uint32_t w = tbl_bits[mini - g];
+                    const uint64_t bit = (uint64_t)tbl_start[mini - g] * 8ull + (uint64_t)(v - mini * per_mini32) * w;
+                    const uint32_t d = (uint32_t)(bit >> 5) * 4u;
+                    const uint32_t sh = (uint32_t)bit & 31u;
+                    const uint32_t x0 = __builtin_amdgcn_raw_buffer_load_b32(rsrc, d, 0, 0);
+                    const uint32_t x1 = __builtin_amdgcn_raw_buffer_load_b32(rsrc, d + 4u, 0, 0);
+                    const uint32_t x2 = __builtin_amdgcn_raw_buffer_load_b32(rsrc, d + 8u, 0, 0);
+                    const uint64_t field = ((uint64_t)__builtin_amdgcn_alignbit(x2, x1, sh) << 32) |
+                                           __builtin_amdgcn_alignbit(x1, x0, sh);
+                    const uint64_t mask = w == 0u ? 0ull : (~0ull >> (64u - w));
+                    term = min_delta + (field & mask);
+                }
+                const uint64_t value = acc + wave_inclusive_sum64(term);
+                if (v < v_end) out[1ull + done + v] = value;
+                acc = lane_value64(value, 63u);  // the lanes behind v_end add nothing
+            }
+            wave_sync();
+        }
+        pos = at;
+        if (block_len == 0u && ++empties == 2u) return 1;  // "Missing block" (decoder.rs:199-206)
+        done += block_len;
+        remaining -= block_len;
+    }
+    consumed = pos - delta;
+    return 0;
+}
+
+__global__ __launch_bounds__(64) void delta_kernel(const DeltaPage *__restrict__ pages, uint32_t n_pages,
+                                                   DeltaResult *__restrict__ results) {
+    __shared__ uint32_t tbl_start[64], tbl_bits[64];
+    const uint32_t page = blockIdx.x;
+    if (page >= n_pages) return;
+    uint64_t num_values = 0ull;
+    uint32_t consumed = 0u;
+    const int32_t status = delta_decode(pages[page], threadIdx.x, tbl_start, tbl_bits, num_values, consumed);
+    if (threadIdx.x == 0u) {
+        DeltaResult r;
+        r.status = status;
+        r.consumed = consumed;
+        r.num_values = num_values;
+        results[page] = r;
+    }
+}
+
 }  // namespace pq2
 
 // ---- launchers (called from pq2_api.cpp) ----------------------------------------
@@ -1434,6 +1622,13 @@ extern "C" hipError_t pq2_launch_bitunpack64(const void *d_packed, uint32_t pack
     const uint32_t blocks = (length + 255u) / 256u;
     hipLaunchKernelGGL(pq2::bitunpack64_kernel, dim3(blocks < 65536u ? blocks : 65536u), dim3(256), 0, stream,
                        (uint64_t)(uintptr_t)d_packed, packed_len, num_bits, length, d_out);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t pq2_launch_delta(const void *pages, uint32_t n_pages, void *results, hipStream_t stream) {
+    if (n_pages == 0) return hipSuccess;
+    hipLaunchKernelGGL(pq2::delta_kernel, dim3(n_pages), dim3(64), 0, stream, (const pq2::DeltaPage *)pages, n_pages,
+                       (pq2::DeltaResult *)results);
     return hipGetLastError();
 }
 

@@ -1,8 +1,9 @@
-"""`parquet2::encoding` (src/encoding/mod.rs): the hybrid-RLE / bit-packing part."""
+"""`parquet2::encoding` (src/encoding/mod.rs): the hybrid-RLE / bit-packing part and DELTA_BINARY_PACKED."""
 import ctypes as C
 
 from .._lib import OK, as_u8, lib, ptr
 from . import bitpacked, hybrid_rle, uleb128  # noqa: F401
+from . import delta_bitpacked  # noqa: F401,E402
 
 
 def ceil8(value):

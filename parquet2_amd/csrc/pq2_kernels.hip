@@ -1442,9 +1442,12 @@ __device__ int32_t delta_decode(const DeltaPage pg, uint32_t lane, uint32_t *tbl
     // value indices stay below 2^31: a mini-block that long holds the whole of any block
     const uint32_t per_mini32 = per_mini > 0x80000000ull ? 0x80000000u : (uint32_t)per_mini;
 
+    // a mini-block's index from a value's index: a shift where the mini-blocks hold a power of two of values
+    const bool minis_pow2 = (per_mini32 & (per_mini32 - 1u)) == 0u;
+    const uint32_t mini_shift = per_mini32 != 0u ? (uint32_t)__builtin_ctz(per_mini32) : 0u;
+    if (remaining != 0u) window = window_at(pos);
     while (remaining != 0u) {
-        // Block::try_new, decoder.rs:26-64
-        window = window_at(pos);
+        // Block::try_new, decoder.rs:26-64; `window` holds the 64 bytes from `pos` on
         const Varint md = varint_at(window, 0u);
         if (md.panics) return 5;
         const uint64_t min_delta = zigzag(md.value);
@@ -1454,10 +1457,16 @@ __device__ int32_t delta_decode(const DeltaPage pg, uint32_t lane, uint32_t *tbl
         // the first mini-block is opened by try_new, each further one after the last value of the one before
         const uint32_t needed = block_len == 0u ? 1u : (block_len - 1u) / per_mini32 + 1u;
         uint32_t at = widths_at + (uint32_t)num_mini_blocks.value;  // where the next mini-block's bytes begin
+        uint32_t next_window = 0u;
         for (uint32_t g = 0; g < needed; g += 64u) {
             // Block::advance_miniblock, decoder.rs:66-91, for the mini-blocks g .. g + 63
             const uint32_t j = g + lane;
-            const uint32_t bits = j < needed ? byte_at(widths_at + j) : 0u;
+            uint32_t bits;
+            if (g == 0u && md.used + needed <= 64u)  // the widths are in the window already
+                bits = (uint32_t)__shfl((int)window, (int)((md.used + lane) & 63u)) & 0xffu;
+            else
+                bits = j < needed ? byte_at(widths_at + j) : 0u;
+            if (j >= needed) bits = 0u;
             uint64_t length = bits != 0u ? (per_mini * bits + 7ull) / 8ull : 0ull;  // ceil8(values_per_mini_block * num_bits)
             if (length > 0x100000000ull) length = 0x100000000ull;                   // more than any stream holds
             const uint64_t upto = wave_inclusive_sum64(length);
@@ -1466,37 +1475,47 @@ __device__ int32_t delta_decode(const DeltaPage pg, uint32_t lane, uint32_t *tbl
             // all (decode.rs:46-50), and unpack64 has no width above 64
             const uint64_t bad = __ballot(short_of || (bits > 64u && length != 0ull));
             if (bad != 0ull) return ((__ballot(short_of) >> __builtin_ctzll(bad)) & 1ull) != 0ull ? 1 : 5;
+            const bool narrow = __ballot(bits > 32u) == 0ull;  // then a field and its shift fit two dwords
             tbl_start[lane] = at + (uint32_t)(upto - length);
             tbl_bits[lane] = bits;
             wave_sync();
             at += (uint32_t)lane_value64(upto, 63u);
+            // the next block's header is asked for before this block's values: its latency is the chain from
+            // block to block, and loads return in the order they were issued
+            if (g + 64u >= needed && remaining != block_len) next_window = window_at(at);
             // Iterator for Block (:93-118) and for Decoder (:216-243): the values of these mini-blocks
             const uint64_t group_end = ((uint64_t)g + 64ull) * per_mini32;
             const uint32_t v_end = group_end < block_len ? (uint32_t)group_end : block_len;
-            for (uint32_t base = g * per_mini32; base < v_end; base += 64u) {
+            auto term_of = [&](uint32_t v) -> uint64_t {  // min_delta + the packed value, 0 behind the last one
+                if (v >= v_end) return 0ull;
+                const uint32_t mini = minis_pow2 ? v >> mini_shift : v / per_mini32;
+                const uint32_t w = tbl_bits[mini - g];
+                const uint64_t bit = (uint64_t)tbl_start[mini - g] * 8ull + (uint64_t)(v - mini * per_mini32) * w;
+                const uint32_t d = (uint32_t)(bit >> 5) * 4u;
+                const uint32_t sh = (uint32_t)bit & 31u;
+                const uint32_t x0 = __builtin_amdgcn_raw_buffer_load_b32(rsrc, d, 0, 0);
+                const uint32_t x1 = __builtin_amdgcn_raw_buffer_load_b32(rsrc, d + 4u, 0, 0);
+                const uint32_t x2 = narrow ? 0u : __builtin_amdgcn_raw_buffer_load_b32(rsrc, d + 8u, 0, 0);
+                const uint64_t field = ((uint64_t)__builtin_amdgcn_alignbit(x2, x1, sh) << 32) |
+                                       __builtin_amdgcn_alignbit(x1, x0, sh);
+                const uint64_t mask = w == 0u ? 0ull : (~0ull >> (64u - w));
+                return min_delta + (field & mask);
+            };
+            // two steps of 64 values at a time: the loads of both are in flight before the first store
+            for (uint32_t base = g * per_mini32; base < v_end; base += 128u) {
                 const uint32_t v = base + lane;
-                uint64_t term = 0ull;
-                if (v < v_end) {
-                    const uint32_t mini = v / per_mini32;
-                    const uint32_t w = tbl_bits[mini - g];
-                    const uint64_t bit = (uint64_t)tbl_start[mini - g] * 8ull + (uint64_t)(v - mini * per_mini32) * w;
-                    const uint32_t d = (uint32_t)(bit >> 5) * 4u;
-                    const uint32_t sh = (uint32_t)bit & 31u;
-                    const uint32_t x0 = __builtin_amdgcn_raw_buffer_load_b32(rsrc, d, 0, 0);
-                    const uint32_t x1 = __builtin_amdgcn_raw_buffer_load_b32(rsrc, d + 4u, 0, 0);
-                    const uint32_t x2 = __builtin_amdgcn_raw_buffer_load_b32(rsrc, d + 8u, 0, 0);
-                    const uint64_t field = ((uint64_t)__builtin_amdgcn_alignbit(x2, x1, sh) << 32) |
-                                           __builtin_amdgcn_alignbit(x1, x0, sh);
-                    const uint64_t mask = w == 0u ? 0ull : (~0ull >> (64u - w));
-                    term = min_delta + (field & mask);
-                }
-                const uint64_t value = acc + wave_inclusive_sum64(term);
-                if (v < v_end) out[1ull + done + v] = value;
-                acc = lane_value64(value, 63u);  // the lanes behind v_end add nothing
+                const uint64_t term0 = term_of(v);
+                const uint64_t term1 = term_of(v + 64u);
+                const uint64_t value0 = acc + wave_inclusive_sum64(term0);
+                const uint64_t value1 = lane_value64(value0, 63u) + wave_inclusive_sum64(term1);
+                if (v < v_end) out[1ull + done + v] = value0;
+                if (v + 64u < v_end) out[1ull + done + v + 64u] = value1;
+                acc = lane_value64(value1, 63u);  // the lanes behind v_end add nothing
             }
             wave_sync();
         }
         pos = at;
+        window = next_window;
         if (block_len == 0u && ++empties == 2u) return 1;  // "Missing block" (decoder.rs:199-206)
         done += block_len;
         remaining -= block_len;

@@ -292,6 +292,19 @@ int32_t pq2_delta_bitpacked_decode_batch_device(pq2_ctx *ctx, const void *d_in, 
 int32_t pq2_delta_bitpacked_decode_host(pq2_ctx *ctx, const void *values, uint64_t len, int64_t *out, uint64_t cap,
                                         uint64_t *num_values, uint64_t *consumed_bytes);
 
+/* Host-side write path of the same encoding (no device work).
+ * delta_bitpacked::encode(iterator, &mut buffer) (src/encoding/delta_bitpacked/encoder.rs:11-78): blocks of 128
+ * values with one mini-block each; byte for byte the reference's output, including the 128-slot array it reuses
+ * from block to block (:27), so the packed slots behind a short last block hold the block before.  The
+ * subtractions wrap as in the reference's release build.  `out_cap` must be at least
+ * pq2_delta_bitpacked_encode_bound(len). */
+uint64_t pq2_delta_bitpacked_encode_bound(uint64_t len);
+int32_t pq2_delta_bitpacked_encode(const int64_t *values, uint64_t len, uint8_t *out, uint64_t out_cap,
+                                   uint64_t *written);
+/* src/encoding/zigzag_leb128.rs:5-8 and :10-15 */
+int32_t pq2_zigzag_leb128_decode(const uint8_t *values, uint64_t len, int64_t *value, uint64_t *consumed);
+uint64_t pq2_zigzag_leb128_encode(int64_t value, uint8_t container[10]);
+
 /* ---- multi-GPU sharding ---------------------------------------------------- */
 
 /* Splits a batch into `n_parts` contiguous page ranges balanced on output

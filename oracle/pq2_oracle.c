@@ -1058,3 +1058,66 @@ int32_t pq2o_delta_bitpacked_decode(const uint8_t *values, size_t len, int64_t *
     *consumed_bytes = consumed_total + (has_block ? block.consumed_bytes : 0);
     return PQ2O_OK;
 }
+
+/* src/encoding/zigzag_leb128.rs:10-15 */
+size_t pq2o_zigzag_leb128_encode(int64_t value, uint8_t container[10]) {
+    uint64_t u = ((uint64_t)value << 1) ^ (uint64_t)(value >> 63);
+    return pq2o_uleb128_encode(u, container);
+}
+
+/* encoder.rs:66-78 write_miniblock: bitpacked::encode::<u64> of all 128 slots (encode.rs:11-36 with two full
+ * chunks of 64, each pack64 into 8 * num_bits bytes of a zeroed region) */
+static size_t delta_write_miniblock(uint8_t *buffer, size_t num_bits, const uint64_t deltas[128]) {
+    if (num_bits == 0) return 0;
+    const size_t bytes = (128 * num_bits + 7) / 8;
+    memset(buffer, 0, bytes);
+    pack64_width(deltas, buffer, (unsigned)num_bits);
+    pack64_width(deltas + 64, buffer + 8 * num_bits, (unsigned)num_bits);
+    return bytes;
+}
+
+/* src/encoding/delta_bitpacked/encoder.rs:11-64.  The subtractions wrap (the reference's release build; its
+ * debug build panics where they overflow).  `buffer` must hold 32 + ceil(len / 128) * 1035 bytes. */
+size_t pq2o_delta_bitpacked_encode(const int64_t *iterator, size_t len, uint8_t *buffer) {
+    uint8_t container[10];
+    size_t at = 0, next = 0;
+    size_t used = pq2o_uleb128_encode(128, container); /* block_size */
+    memcpy(buffer + at, container, used), at += used;
+    used = pq2o_uleb128_encode(1, container); /* mini_blocks */
+    memcpy(buffer + at, container, used), at += used;
+    used = pq2o_uleb128_encode((uint64_t)len, container);
+    memcpy(buffer + at, container, used), at += used;
+
+    int64_t values[128] = {0};
+    uint64_t deltas[128] = {0};
+    int64_t first_value = next < len ? iterator[next++] : 0; /* unwrap_or_default */
+    used = pq2o_zigzag_leb128_encode(first_value, container);
+    memcpy(buffer + at, container, used), at += used;
+
+    int64_t prev = first_value;
+    size_t length = len - next;
+    while (length != 0) {
+        int64_t min_delta = INT64_MAX, max_delta = INT64_MIN;
+        unsigned num_bits = 0;
+        size_t consumed = 0;
+        for (size_t i = 0; i < 128 && next < len; ++i) { /* (0..128).zip(&mut iterator) */
+            int64_t integer = iterator[next++];
+            int64_t delta = (int64_t)((uint64_t)integer - (uint64_t)prev);
+            if (delta < min_delta) min_delta = delta;
+            if (delta > max_delta) max_delta = delta;
+            uint64_t range = (uint64_t)max_delta - (uint64_t)min_delta;
+            num_bits = range == 0 ? 0 : 64 - (unsigned)__builtin_clzll(range);
+            values[i] = delta;
+            prev = integer;
+            consumed = i + 1;
+        }
+        length = len - next;
+        /* the slots behind `consumed` keep the deltas of the block before (:27, :52-54) */
+        for (size_t i = 0; i < consumed; ++i) deltas[i] = (uint64_t)values[i] - (uint64_t)min_delta;
+        used = pq2o_zigzag_leb128_encode(min_delta, container);
+        memcpy(buffer + at, container, used), at += used;
+        buffer[at++] = (uint8_t)num_bits;
+        at += delta_write_miniblock(buffer + at, num_bits, deltas);
+    }
+    return at;
+}

@@ -226,6 +226,12 @@ double pq2o_time_hybrid_rle_decode(const uint8_t *data, size_t len, uint32_t num
 double pq2o_time_bitunpack_u32(const uint8_t *packed, size_t packed_len, size_t num_bits, size_t length,
                                uint32_t *out, int reps);
 
+/* src/encoding/zigzag_leb128.rs:10-15 */
+size_t pq2o_zigzag_leb128_encode(int64_t value, uint8_t container[10]);
+/* delta_bitpacked::encode (src/encoding/delta_bitpacked/encoder.rs:11-78): returns the bytes written; `buffer`
+ * must hold 32 + ceil(len / 128) * 1035 bytes. */
+size_t pq2o_delta_bitpacked_encode(const int64_t *iterator, size_t len, uint8_t *buffer);
+
 #ifdef __cplusplus
 }
 #endif

@@ -94,6 +94,10 @@ SIGNATURES = {
                                                              C.c_void_p, C.c_void_p]),
     "pq2_delta_bitpacked_decode_host": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, u64p,
                                                      u64p]),
+    "pq2_delta_bitpacked_encode_bound": (C.c_uint64, [C.c_uint64]),
+    "pq2_delta_bitpacked_encode": (C.c_int32, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, u64p]),
+    "pq2_zigzag_leb128_decode": (C.c_int32, [C.c_void_p, C.c_uint64, C.POINTER(C.c_int64), u64p]),
+    "pq2_zigzag_leb128_encode": (C.c_uint64, [C.c_int64, u8p]),
     "pq2_partition_pages": (C.c_int32, [C.c_void_p, C.c_uint64, C.c_uint32, u64p]),
     "pq2_ceil8": (C.c_uint64, [C.c_uint64]),
     "pq2_get_length": (C.c_int32, [C.c_void_p, C.c_uint64, u64p]),

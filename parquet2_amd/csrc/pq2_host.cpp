@@ -230,3 +230,88 @@ int32_t pq2_hybrid_rle_encode_bool(const uint8_t *bools, uint64_t len, uint8_t *
 }
 
 }  // extern "C"
+
+// ---- DELTA_BINARY_PACKED, write side ------------------------------------------------------
+
+namespace {
+
+// 64 values at `width` bits OR-ed into `width` little-endian qwords at `out`, with the split rule of
+// src/encoding/bitpacked/pack.rs:27-46 (see pack_block_u32).
+void pack_block_u64(const uint64_t *in, uint32_t width, uint8_t *out) {
+    if (width == 0) return;
+    const uint64_t mask = width == 64 ? ~0ull : (1ull << width) - 1ull;
+    uint64_t words[64] = {0};
+    for (uint32_t i = 0; i < 64; ++i) {
+        const uint32_t first = i * width, last = first + width;
+        const uint32_t w0 = first / 64, w1 = last / 64, lo = first % 64, hi = last % 64;
+        if (w0 != w1 && hi != 0) {
+            words[w0] |= in[i] << lo;
+            words[w1] |= (in[i] >> (width - hi)) & mask;
+        } else {
+            words[w0] |= (in[i] & mask) << lo;
+        }
+    }
+    for (uint32_t k = 0; k < width; ++k) {
+        uint8_t le[8];
+        std::memcpy(le, &words[k], 8);
+        for (int b = 0; b < 8; ++b) out[8 * k + b] |= le[b];
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t pq2_zigzag_leb128_decode(const uint8_t *values, uint64_t len, int64_t *value, uint64_t *consumed) {
+    uint64_t u = 0;
+    const int32_t st = pq2_uleb128_decode(values, len, &u, consumed);
+    if (st != PQ2_OK) return st;
+    *value = static_cast<int64_t>(u >> 1) ^ -static_cast<int64_t>(u & 1);
+    return PQ2_OK;
+}
+
+uint64_t pq2_zigzag_leb128_encode(int64_t value, uint8_t container[10]) {
+    return pq2_uleb128_encode((static_cast<uint64_t>(value) << 1) ^ static_cast<uint64_t>(value >> 63), container);
+}
+
+uint64_t pq2_delta_bitpacked_encode_bound(uint64_t len) { return 32 + ((len + 127) / 128) * (10 + 1 + 16 * 64); }
+
+int32_t pq2_delta_bitpacked_encode(const int64_t *values, uint64_t len, uint8_t *out, uint64_t out_cap,
+                                   uint64_t *written) {
+    if (out_cap < pq2_delta_bitpacked_encode_bound(len)) return PQ2_INVALID_PARAMETER;
+    uint8_t *dst = out;
+    dst += pq2_uleb128_encode(128, dst);  // block size
+    dst += pq2_uleb128_encode(1, dst);    // one mini-block per block
+    dst += pq2_uleb128_encode(len, dst);
+    const int64_t first = len ? values[0] : 0;
+    dst += pq2_zigzag_leb128_encode(first, dst);
+    // One array of 128 slots serves every block, as in the reference (encoder.rs:27): the slots behind a short
+    // last block still hold the block before, and all 128 are packed.
+    uint64_t rel[128] = {0};
+    uint64_t prev = static_cast<uint64_t>(first);
+    for (uint64_t at = 1; at < len; at += 128) {
+        const uint64_t n = len - at < 128 ? len - at : 128;
+        int64_t delta[128];
+        int64_t low = INT64_MAX, high = INT64_MIN;
+        for (uint64_t i = 0; i < n; ++i) {
+            const uint64_t v = static_cast<uint64_t>(values[at + i]);
+            delta[i] = static_cast<int64_t>(v - prev);  // wraps, as the reference's release build
+            prev = v;
+            low = delta[i] < low ? delta[i] : low;
+            high = delta[i] > high ? delta[i] : high;
+        }
+        const uint64_t range = static_cast<uint64_t>(high) - static_cast<uint64_t>(low);
+        const uint32_t width = range ? 64u - static_cast<uint32_t>(__builtin_clzll(range)) : 0u;
+        for (uint64_t i = 0; i < n; ++i) rel[i] = static_cast<uint64_t>(delta[i]) - static_cast<uint64_t>(low);
+        dst += pq2_zigzag_leb128_encode(low, dst);
+        *dst++ = static_cast<uint8_t>(width);
+        std::memset(dst, 0, 16ull * width);
+        pack_block_u64(rel, width, dst);
+        pack_block_u64(rel + 64, width, dst + 8ull * width);
+        dst += 16ull * width;
+    }
+    *written = static_cast<uint64_t>(dst - out);
+    return PQ2_OK;
+}
+
+}  // extern "C"

@@ -3,7 +3,7 @@ import ctypes as C
 
 from .._lib import OK, as_u8, lib, ptr
 from . import bitpacked, hybrid_rle, uleb128  # noqa: F401
-from . import delta_bitpacked  # noqa: F401,E402
+from . import delta_bitpacked, zigzag_leb128  # noqa: F401,E402
 
 
 def ceil8(value):

@@ -1,9 +1,14 @@
 """`parquet2::encoding::delta_bitpacked` (src/encoding/delta_bitpacked/): DELTA_BINARY_PACKED integers.
 
 `Decoder` decodes on the GPU (delta_kernel): the blocks of a stream one after the other, the values of a block
-lane-parallel with a 64-bit prefix sum over the deltas.
+lane-parallel with a 64-bit prefix sum over the deltas.  `encode` is the host-side write path.
 """
-from .._lib import as_u8, default_context
+import ctypes as C
+
+import numpy as np
+
+from .._lib import as_u8, default_context, lib, ptr
+from ..error import raise_for_status
 from . import uleb128
 
 # more values than this in one stream are refused by the library (PQ2_MAX_PAGE_VALUES)
@@ -54,3 +59,18 @@ class Decoder:
 
     def __len__(self):
         return len(self._values) - self._pos
+
+
+def encode(iterator, buffer=None):
+    """`delta_bitpacked::encode(iterator, &mut buffer)` (encoder.rs:11-78), on the host.  Returns the bytes, or
+    appends them to the given bytearray."""
+    v = np.ascontiguousarray(list(iterator) if not isinstance(iterator, np.ndarray) else iterator, dtype=np.int64)
+    out = np.zeros(lib().pq2_delta_bitpacked_encode_bound(v.size), dtype=np.uint8)
+    written = C.c_uint64()
+    raise_for_status(lib().pq2_delta_bitpacked_encode(ptr(v), v.size, ptr(out), out.size, C.byref(written)),
+                     "delta_bitpacked::encode")
+    data = out[:written.value].tobytes()
+    if buffer is None:
+        return data
+    buffer.extend(data)
+    return None

@@ -90,6 +90,10 @@ class Oracle:
         lib.pq2o_bitunpack_u64.argtypes = [u8p, sz, sz, sz, u64p]
         lib.pq2o_zigzag_leb128_decode.argtypes = [u8p, sz, C.POINTER(C.c_int64), C.POINTER(sz)]
         lib.pq2o_delta_bitpacked_decode.argtypes = [u8p, sz, C.POINTER(C.c_int64), sz, C.POINTER(sz), C.POINTER(sz)]
+        lib.pq2o_zigzag_leb128_encode.restype = sz
+        lib.pq2o_zigzag_leb128_encode.argtypes = [C.c_int64, C.POINTER(C.c_uint8)]
+        lib.pq2o_delta_bitpacked_encode.restype = sz
+        lib.pq2o_delta_bitpacked_encode.argtypes = [C.POINTER(C.c_int64), sz, u8p]
         lib.pq2o_run_decoder_new.restype = None
         lib.pq2o_run_decoder_new.argtypes = [C.POINTER(RunDecoder), u8p, sz, sz]
         lib.pq2o_run_decoder_next.argtypes = [C.POINTER(RunDecoder), C.POINTER(HybridEncoded)]
@@ -185,6 +189,17 @@ class Oracle:
         st = self.lib.pq2o_delta_bitpacked_decode(_ptr(a), a.size, out.ctypes.data_as(C.POINTER(C.c_int64)), cap,
                                                   C.byref(n), C.byref(c))
         return st, out[:min(n.value, cap)], c.value
+
+    def zigzag_leb128_encode(self, value):
+        buf = (C.c_uint8 * 10)()
+        n = self.lib.pq2o_zigzag_leb128_encode(C.c_int64(value), buf)
+        return bytes(buf[:n])
+
+    def delta_bitpacked_encode(self, values):
+        v = np.ascontiguousarray(values, dtype=np.int64)
+        out = np.zeros(32 + ((v.size + 127) // 128) * 1035, dtype=np.uint8)
+        n = self.lib.pq2o_delta_bitpacked_encode(v.ctypes.data_as(C.POINTER(C.c_int64)), v.size, _ptr(out))
+        return out[:n].tobytes()
 
     # -- hybrid rle -------------------------------------------------------
     def runs(self, data, num_bits):

@@ -216,6 +216,28 @@ def main():
          "consumed": 38},
     ]
 
+    kats["zigzag_leb128_encode"] = {
+        "src": "src/encoding/zigzag_leb128.rs:45-64 test_encode",
+        "cases": [[0, 0], [1, -1], [2, 1], [3, -2], [4, 2], [5, -3], [6, 3], [7, -4], [8, 4], [9, -5]],
+    }
+    kats["delta_bitpacked_encode"] = [
+        {"src": "src/encoding/delta_bitpacked/encoder.rs:84-100 constant_delta",
+         "data": [1, 2, 3, 4, 5], "expected": [128, 1, 1, 5, 2, 2, 0]},
+        {"src": "src/encoding/delta_bitpacked/encoder.rs:102-124 negative_min_delta",
+         "data": [1, 2, 3, 4, 5, 1],
+         "expected": [128, 1, 1, 6, 2, 7, 3, 0b01101101, 0b00001011] + [0] * (128 * 3 // 8 - 2)},
+    ]
+    # encode -> Decoder gives the data back (src/encoding/delta_bitpacked/mod.rs:13-90); test_another also
+    # checks consumed_bytes() == buffer.len()
+    kats["delta_bitpacked_round_trip"] = [
+        {"src": "mod.rs:13-24 basic", "data": [1, 3, 1, 2, 3]},
+        {"src": "mod.rs:26-37 negative_value", "data": [1, 3, -1, 2, 3]},
+        {"src": "mod.rs:39-58 some",
+         "data": [-2147483648, -1777158217, -984917788, -1533539476, -731221386, -1322398478, 906736096]},
+        {"src": "mod.rs:60-74 more_than_one_block", "data": [1, 3, -1, 2, 3, 10, 1] + [x - 10 for x in range(128)]},
+        {"src": "mod.rs:76-90 test_another", "data": [2, 3, 1, 2, 1], "consumed_is_len": True},
+    ]
+
     with open(OUT, "w") as f:
         json.dump(kats, f, indent=1)
         f.write("\n")

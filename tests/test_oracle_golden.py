@@ -213,3 +213,16 @@ def test_zigzag_and_delta_bitpacked(oracle, kats):
     for c in kats["delta_bitpacked_decode"]:
         st, values, consumed = oracle.delta_bitpacked_decode(bytes(c["data"]), len(c["expected"]))
         assert st == 0 and values.tolist() == c["expected"] and consumed == c["consumed"], c["src"]
+
+
+def test_delta_bitpacked_encoder(oracle, kats):
+    for byte, value in kats["zigzag_leb128_encode"]["cases"]:
+        assert oracle.zigzag_leb128_encode(value) == bytes([byte])
+    for c in kats["delta_bitpacked_encode"]:
+        assert oracle.delta_bitpacked_encode(c["data"]) == bytes(c["expected"]), c["src"]
+    for c in kats["delta_bitpacked_round_trip"]:
+        buf = oracle.delta_bitpacked_encode(c["data"])
+        st, values, consumed = oracle.delta_bitpacked_decode(buf, len(c["data"]))
+        assert st == 0 and values.tolist() == c["data"], c["src"]
+        if c.get("consumed_is_len"):
+            assert consumed == len(buf)

@@ -1400,21 +1400,38 @@ __device__ __forceinline__ Varint varint_at(uint32_t window, uint32_t o) {
 }
 __device__ __forceinline__ uint64_t zigzag(uint64_t u) { return (u >> 1) ^ (0ull - (u & 1ull)); }
 
-// The decode of one stream by one wave; returns the status.  `tbl_start` / `tbl_bits`: 64 LDS words each.
-__device__ int32_t delta_decode(const DeltaPage pg, uint32_t lane, uint32_t *tbl_start, uint32_t *tbl_bits,
-                                uint64_t &num_values, uint32_t &consumed) {
-    const uint32_t delta = (uint32_t)(pg.in_addr & 15u);
-    const uint32_t end = delta + pg.in_len;
-    const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(pg.in_addr - delta, (end + 3u) & ~3u);
-    uint64_t *out = (uint64_t *)pg.out_addr;
-    auto byte_at = [&](uint32_t a) -> uint32_t {
-        return (__builtin_amdgcn_raw_buffer_load_b32(rsrc, a & ~3u, 0, 0) >> ((a & 3u) * 8u)) & 0xffu;
-    };
-    auto window_at = [&](uint32_t a) -> uint32_t { return a + lane < end ? byte_at(a + lane) : 0x100u; };
+// A stream behind its header, as every lane of a wave holds it.
+struct DeltaStream {
+    __amdgpu_buffer_rsrc_t rsrc;  // the stream from its 16-byte aligned base on ("a-offsets")
+    uint32_t delta, end;          // a-offsets of the first byte and behind the last one
+    uint64_t *out;
+    uint64_t num_mini_blocks, per_mini, block_most;  // block_most: values of a whole block (<= block_size)
+    uint32_t per_mini32;                             // per_mini, capped: value indices stay below 2^31
+    uint32_t block_size_small;                       // block_size where it is at most 4096, else 0
+    // where the decode stands
+    uint32_t pos;        // a-offset of the next block
+    uint32_t remaining;  // deltas still to take
+    uint32_t done;       // deltas taken
+    uint32_t empties;
+    uint64_t acc;        // the last value
+};
 
-    // Decoder::try_new, decoder.rs:136-180
-    uint32_t pos = delta;
-    uint32_t window = window_at(pos);
+__device__ __forceinline__ uint32_t delta_byte_at(const DeltaStream &s, uint32_t a) {
+    return (__builtin_amdgcn_raw_buffer_load_b32(s.rsrc, a & ~3u, 0, 0) >> ((a & 3u) * 8u)) & 0xffu;
+}
+// one stream byte per lane from `a` on; bit 8 set behind the stream's end
+__device__ __forceinline__ uint32_t delta_window_at(const DeltaStream &s, uint32_t a, uint32_t lane) {
+    return a + lane < s.end ? delta_byte_at(s, a + lane) : 0x100u;
+}
+
+// Decoder::try_new, decoder.rs:136-180.  Returns the stream's status, or -1 with `s` set up where blocks follow.
+__device__ int32_t delta_open(const DeltaPage pg, uint32_t lane, bool store_first, DeltaStream &s,
+                              uint64_t &num_values) {
+    s.delta = (uint32_t)(pg.in_addr & 15u);
+    s.end = s.delta + pg.in_len;
+    s.rsrc = make_rsrc(pg.in_addr - s.delta, (s.end + 3u) & ~3u);
+    s.out = (uint64_t *)pg.out_addr;
+    const uint32_t window = delta_window_at(s, s.delta, lane);
     const Varint block_size = varint_at(window, 0u);
     if (block_size.panics || (block_size.value & 127ull) != 0ull) return 5;  // assert_eq!(block_size % 128, 0)
     uint32_t o = block_size.used;
@@ -1428,35 +1445,43 @@ __device__ int32_t delta_decode(const DeltaPage pg, uint32_t lane, uint32_t *tbl
     if (first.panics) return 5;
     o += first.used;
     if (num_mini_blocks.value == 0ull) return 5;  // block_size / num_mini_blocks
-    const uint64_t per_mini = block_size.value / num_mini_blocks.value;
-    if ((per_mini & 7ull) != 0ull) return 5;  // assert_eq!(values_per_mini_block % 8, 0)
+    s.num_mini_blocks = num_mini_blocks.value;
+    s.per_mini = block_size.value / num_mini_blocks.value;
+    if ((s.per_mini & 7ull) != 0ull) return 5;  // assert_eq!(values_per_mini_block % 8, 0)
     num_values = total_count.value;
     if (total_count.value > pg.cap) return 2;
-    pos += o;
+    s.pos = s.delta + o;
+    s.acc = zigzag(first.value);
+    if (total_count.value != 0ull && lane == 0u && store_first) s.out[0] = s.acc;
+    s.remaining = total_count.value != 0ull ? (uint32_t)total_count.value - 1u : 0u;
+    s.done = 0u, s.empties = 0u;
+    s.block_most = s.num_mini_blocks * s.per_mini;
+    s.per_mini32 = s.per_mini > 0x80000000ull ? 0x80000000u : (uint32_t)s.per_mini;
+    s.block_size_small = block_size.value <= 4096ull ? (uint32_t)block_size.value : 0u;
+    return s.remaining == 0u ? 0 : -1;
+}
 
-    uint64_t acc = zigzag(first.value);
-    if (total_count.value != 0ull && lane == 0u) out[0] = acc;
-    uint32_t remaining = total_count.value != 0ull ? (uint32_t)total_count.value - 1u : 0u;  // deltas still to take
-    uint32_t done = 0u, empties = 0u;
-    const uint64_t block_most = num_mini_blocks.value * per_mini;  // <= block_size
-    // value indices stay below 2^31: a mini-block that long holds the whole of any block
-    const uint32_t per_mini32 = per_mini > 0x80000000ull ? 0x80000000u : (uint32_t)per_mini;
-
+// The blocks of a stream from where `s` stands, one after the other, by one wave; returns the status.  This is
+// the path for every shape of stream and the one that finds what is wrong with a stream.  `tbl_start` /
+// `tbl_bits`: 64 LDS words each.
+__device__ int32_t delta_blocks(DeltaStream &s, uint32_t lane, uint32_t *tbl_start, uint32_t *tbl_bits) {
+    const uint32_t end = s.end;
+    const uint32_t per_mini32 = s.per_mini32;
     // a mini-block's index from a value's index: a shift where the mini-blocks hold a power of two of values
     const bool minis_pow2 = (per_mini32 & (per_mini32 - 1u)) == 0u;
     const uint32_t mini_shift = per_mini32 != 0u ? (uint32_t)__builtin_ctz(per_mini32) : 0u;
-    if (remaining != 0u) window = window_at(pos);
-    while (remaining != 0u) {
+    uint32_t window = s.remaining != 0u ? delta_window_at(s, s.pos, lane) : 0u;
+    while (s.remaining != 0u) {
         // Block::try_new, decoder.rs:26-64; `window` holds the 64 bytes from `pos` on
         const Varint md = varint_at(window, 0u);
         if (md.panics) return 5;
         const uint64_t min_delta = zigzag(md.value);
-        const uint32_t widths_at = pos + md.used;
-        if (num_mini_blocks.value > (uint64_t)(end - widths_at)) return 1;  // "Block must contain at least..."
-        const uint32_t block_len = (uint64_t)remaining < block_most ? remaining : (uint32_t)block_most;
+        const uint32_t widths_at = s.pos + md.used;
+        if (s.num_mini_blocks > (uint64_t)(end - widths_at)) return 1;  // "Block must contain at least..."
+        const uint32_t block_len = (uint64_t)s.remaining < s.block_most ? s.remaining : (uint32_t)s.block_most;
         // the first mini-block is opened by try_new, each further one after the last value of the one before
         const uint32_t needed = block_len == 0u ? 1u : (block_len - 1u) / per_mini32 + 1u;
-        uint32_t at = widths_at + (uint32_t)num_mini_blocks.value;  // where the next mini-block's bytes begin
+        uint32_t at = widths_at + (uint32_t)s.num_mini_blocks;  // where the next mini-block's bytes begin
         uint32_t next_window = 0u;
         for (uint32_t g = 0; g < needed; g += 64u) {
             // Block::advance_miniblock, decoder.rs:66-91, for the mini-blocks g .. g + 63
@@ -1465,10 +1490,10 @@ __device__ int32_t delta_decode(const DeltaPage pg, uint32_t lane, uint32_t *tbl
             if (g == 0u && md.used + needed <= 64u)  // the widths are in the window already
                 bits = (uint32_t)__shfl((int)window, (int)((md.used + lane) & 63u)) & 0xffu;
             else
-                bits = j < needed ? byte_at(widths_at + j) : 0u;
+                bits = j < needed ? delta_byte_at(s, widths_at + j) : 0u;
             if (j >= needed) bits = 0u;
-            uint64_t length = bits != 0u ? (per_mini * bits + 7ull) / 8ull : 0ull;  // ceil8(values_per_mini_block * num_bits)
-            if (length > 0x100000000ull) length = 0x100000000ull;                   // more than any stream holds
+            uint64_t length = bits != 0u ? (s.per_mini * bits + 7ull) / 8ull : 0ull;  // ceil8(values_per_mini_block * num_bits)
+            if (length > 0x100000000ull) length = 0x100000000ull;                     // more than any stream holds
             const uint64_t upto = wave_inclusive_sum64(length);
             const bool short_of = bits != 0u && upto > (uint64_t)(end - at);  // "block must contain at least miniblock_length bytes"
             // bitpacked::Decoder::<u64>::try_new(..).unwrap() unpacks the first pack, unless there are no bytes at
@@ -1482,7 +1507,7 @@ __device__ int32_t delta_decode(const DeltaPage pg, uint32_t lane, uint32_t *tbl
             at += (uint32_t)lane_value64(upto, 63u);
             // the next block's header is asked for before this block's values: its latency is the chain from
             // block to block, and loads return in the order they were issued
-            if (g + 64u >= needed && remaining != block_len) next_window = window_at(at);
+            if (g + 64u >= needed && s.remaining != block_len) next_window = delta_window_at(s, at, lane);
             // Iterator for Block (:93-118) and for Decoder (:216-243): the values of these mini-blocks
             const uint64_t group_end = ((uint64_t)g + 64ull) * per_mini32;
             const uint32_t v_end = group_end < block_len ? (uint32_t)group_end : block_len;
@@ -1493,9 +1518,9 @@ __device__ int32_t delta_decode(const DeltaPage pg, uint32_t lane, uint32_t *tbl
                 const uint64_t bit = (uint64_t)tbl_start[mini - g] * 8ull + (uint64_t)(v - mini * per_mini32) * w;
                 const uint32_t d = (uint32_t)(bit >> 5) * 4u;
                 const uint32_t sh = (uint32_t)bit & 31u;
-                const uint32_t x0 = __builtin_amdgcn_raw_buffer_load_b32(rsrc, d, 0, 0);
-                const uint32_t x1 = __builtin_amdgcn_raw_buffer_load_b32(rsrc, d + 4u, 0, 0);
-                const uint32_t x2 = narrow ? 0u : __builtin_amdgcn_raw_buffer_load_b32(rsrc, d + 8u, 0, 0);
+                const uint32_t x0 = __builtin_amdgcn_raw_buffer_load_b32(s.rsrc, d, 0, 0);
+                const uint32_t x1 = __builtin_amdgcn_raw_buffer_load_b32(s.rsrc, d + 4u, 0, 0);
+                const uint32_t x2 = narrow ? 0u : __builtin_amdgcn_raw_buffer_load_b32(s.rsrc, d + 8u, 0, 0);
                 const uint64_t field = ((uint64_t)__builtin_amdgcn_alignbit(x2, x1, sh) << 32) |
                                        __builtin_amdgcn_alignbit(x1, x0, sh);
                 const uint64_t mask = w == 0u ? 0ull : (~0ull >> (64u - w));
@@ -1506,39 +1531,181 @@ __device__ int32_t delta_decode(const DeltaPage pg, uint32_t lane, uint32_t *tbl
                 const uint32_t v = base + lane;
                 const uint64_t term0 = term_of(v);
                 const uint64_t term1 = term_of(v + 64u);
-                const uint64_t value0 = acc + wave_inclusive_sum64(term0);
+                const uint64_t value0 = s.acc + wave_inclusive_sum64(term0);
                 const uint64_t value1 = lane_value64(value0, 63u) + wave_inclusive_sum64(term1);
-                if (v < v_end) out[1ull + done + v] = value0;
-                if (v + 64u < v_end) out[1ull + done + v + 64u] = value1;
-                acc = lane_value64(value1, 63u);  // the lanes behind v_end add nothing
+                if (v < v_end) s.out[1ull + s.done + v] = value0;
+                if (v + 64u < v_end) s.out[1ull + s.done + v + 64u] = value1;
+                s.acc = lane_value64(value1, 63u);  // the lanes behind v_end add nothing
             }
             wave_sync();
         }
-        pos = at;
+        s.pos = at;
         window = next_window;
-        if (block_len == 0u && ++empties == 2u) return 1;  // "Missing block" (decoder.rs:199-206)
-        done += block_len;
-        remaining -= block_len;
+        if (block_len == 0u && ++s.empties == 2u) return 1;  // "Missing block" (decoder.rs:199-206)
+        s.done += block_len;
+        s.remaining -= block_len;
     }
-    consumed = pos - delta;
     return 0;
 }
 
-__global__ __launch_bounds__(64) void delta_kernel(const DeltaPage *__restrict__ pages, uint32_t n_pages,
-                                                   DeltaResult *__restrict__ results) {
+// One workgroup of four waves per stream.  Streams of the usual shape (blocks of at most 512 values in at most 16
+// mini-blocks) go chunk by chunk: the workgroup loads 8 KiB of the stream into LDS -- the only time these bytes
+// are read from memory --, wave 0 walks the block headers inside the chunk (a chain of LDS reads instead of one
+// of memory round trips) and lists every block that lies in the chunk whole and is well-formed, the four waves
+// sum the deltas of the listed blocks, a prefix sum over the block sums gives every block its first value, and
+// the waves extract the deltas once more and store the values.  Where the walk lists nothing -- a block that is
+// cut, malformed or absurd -- and for every other shape of stream, wave 0 goes on alone with delta_blocks from
+// that block on, which also decides the stream's status: the chunked path accepts only what delta_blocks accepts.
+constexpr uint32_t kDeltaChunk = 8192;   // bytes of the stream in LDS
+constexpr uint32_t kDeltaListed = 64;    // blocks listed per chunk
+constexpr uint32_t kDeltaMinis = 16;     // mini-blocks per block on the chunked path
+constexpr uint32_t kDeltaBlockMost = 512;  // values per block on the chunked path (10 + 16 + 512 * 8 bytes < chunk)
+
+__global__ __launch_bounds__(256) void delta_kernel(const DeltaPage *__restrict__ pages, uint32_t n_pages,
+                                                    DeltaResult *__restrict__ results) {
+    __shared__ __attribute__((aligned(16))) uint8_t chunk[kDeltaChunk + 32];
+    __shared__ uint16_t mini_start[kDeltaListed * kDeltaMinis];  // byte offset in the chunk
+    __shared__ uint8_t mini_bits[kDeltaListed * kDeltaMinis];
+    __shared__ uint64_t blk_min[kDeltaListed], blk_sum[kDeltaListed];  // blk_sum: the block's sum, then the value before its first
+    __shared__ uint32_t blk_len[kDeltaListed], blk_first[kDeltaListed];
     __shared__ uint32_t tbl_start[64], tbl_bits[64];
+    __shared__ uint32_t stand[4];  // listed blocks; pos, remaining, done behind them
+    __shared__ uint64_t stand_acc;
+
     const uint32_t page = blockIdx.x;
     if (page >= n_pages) return;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u;
+    DeltaStream s;
     uint64_t num_values = 0ull;
-    uint32_t consumed = 0u;
-    const int32_t status = delta_decode(pages[page], threadIdx.x, tbl_start, tbl_bits, num_values, consumed);
-    if (threadIdx.x == 0u) {
-        DeltaResult r;
-        r.status = status;
-        r.consumed = consumed;
-        r.num_values = num_values;
-        results[page] = r;
+    // every wave reads the header for itself: all four hold the same stream state without an exchange
+    int32_t status = delta_open(pages[page], lane, wave == 0u, s, num_values);
+    auto report = [&](int32_t st) {
+        if (threadIdx.x == 0u) {
+            DeltaResult r;
+            r.status = st;
+            r.consumed = st == 0 ? s.pos - s.delta : 0u;
+            r.num_values = num_values;
+            results[page] = r;
+        }
+    };
+    if (status >= 0) {
+        report(status);
+        return;
     }
+    const uint32_t per_mini32 = s.per_mini32;
+    const bool chunked = s.block_size_small != 0u && s.block_size_small <= kDeltaBlockMost &&
+                         s.num_mini_blocks <= kDeltaMinis && per_mini32 != 0u;
+    if (chunked) {
+        const bool minis_pow2 = (per_mini32 & (per_mini32 - 1u)) == 0u;
+        const uint32_t mini_shift = (uint32_t)__builtin_ctz(per_mini32);
+        const uint32_t block_most = (uint32_t)s.block_most;
+        const uint32_t minis = (uint32_t)s.num_mini_blocks;
+        if (threadIdx.x < 2u) *(u32x4 *)(chunk + kDeltaChunk + threadIdx.x * 16u) = u32x4{0u, 0u, 0u, 0u};
+        for (;;) {
+            const uint32_t chunk_a = s.pos & ~15u;
+            const uint32_t chunk_hi = chunk_a + kDeltaChunk;
+            {
+                const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(s.rsrc, chunk_a + threadIdx.x * 16u, 0, 0);
+                const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(s.rsrc, chunk_a + 4096u + threadIdx.x * 16u, 0, 0);
+                *(u32x4 *)(chunk + threadIdx.x * 16u) = a;
+                *(u32x4 *)(chunk + 4096u + threadIdx.x * 16u) = b;
+            }
+            __syncthreads();
+            if (wave == 0u) {
+                // Block::try_new and advance_miniblock as in delta_blocks, out of the chunk; anything but a
+                // well-formed block that lies in the chunk whole ends the list
+                uint32_t listed = 0u, pos = s.pos, remaining = s.remaining, done = s.done;
+                while (remaining != 0u && listed < kDeltaListed) {
+                    if (!(pos + 64u <= chunk_hi || s.end <= chunk_hi)) break;
+                    const uint32_t a = pos + lane;
+                    const uint32_t window = a < s.end ? chunk[a - chunk_a] : 0x100u;
+                    const Varint md = varint_at(window, 0u);
+                    if (md.panics) break;
+                    const uint32_t widths_at = pos + md.used;
+                    if (minis > s.end - widths_at) break;
+                    const uint32_t block_len = remaining < block_most ? remaining : block_most;
+                    const uint32_t needed = (block_len - 1u) / per_mini32 + 1u;
+                    const uint32_t at = widths_at + minis;
+                    // (the shuffle by all lanes: a lane that is switched off hands nothing over)
+                    const uint32_t behind = (uint32_t)__shfl((int)window, (int)((md.used + lane) & 63u)) & 0xffu;
+                    const uint32_t bits = lane < needed ? behind : 0u;
+                    const uint32_t length = bits != 0u ? (per_mini32 * bits + 7u) / 8u : 0u;
+                    const uint32_t upto = wave_inclusive_sum(length);
+                    if (__ballot((bits != 0u && upto > s.end - at) || bits > 64u) != 0ull) break;
+                    const uint32_t total = __builtin_amdgcn_readlane(upto, 63);
+                    if (at + total > chunk_hi) break;
+                    if (lane < kDeltaMinis) {
+                        mini_start[listed * kDeltaMinis + lane] = (uint16_t)(at + upto - length - chunk_a);
+                        mini_bits[listed * kDeltaMinis + lane] = (uint8_t)bits;
+                    }
+                    if (lane == 0u) {
+                        blk_min[listed] = zigzag(md.value);
+                        blk_len[listed] = block_len;
+                        blk_first[listed] = done;
+                    }
+                    pos = at + total;
+                    done += block_len;
+                    remaining -= block_len;
+                    ++listed;
+                }
+                if (lane == 0u) stand[0] = listed, stand[1] = pos, stand[2] = remaining, stand[3] = done;
+            }
+            __syncthreads();
+            const uint32_t listed = stand[0];
+            if (listed == 0u) break;
+            // min_delta + the packed value v of listed block k
+            auto term_of = [&](uint32_t k, uint32_t v, uint64_t min_delta) -> uint64_t {
+                const uint32_t mini = minis_pow2 ? v >> mini_shift : v / per_mini32;
+                const uint32_t w = mini_bits[k * kDeltaMinis + mini];
+                const uint32_t bit = (uint32_t)mini_start[k * kDeltaMinis + mini] * 8u + (v - mini * per_mini32) * w;
+                const uint32_t *src = (const uint32_t *)(chunk + ((bit >> 5) << 2));
+                const uint32_t sh = bit & 31u;
+                const uint32_t x0 = src[0], x1 = src[1], x2 = w > 32u ? src[2] : 0u;
+                const uint64_t field = ((uint64_t)__builtin_amdgcn_alignbit(x2, x1, sh) << 32) |
+                                       __builtin_amdgcn_alignbit(x1, x0, sh);
+                const uint64_t mask = w == 0u ? 0ull : (~0ull >> (64u - w));
+                return min_delta + (field & mask);
+            };
+            for (uint32_t k = wave; k < listed; k += 4u) {  // the sum of every listed block
+                const uint32_t len = blk_len[k];
+                const uint64_t min_delta = blk_min[k];
+                uint64_t sum = 0ull;
+                for (uint32_t v = lane; v < len; v += 64u) sum += term_of(k, v, min_delta);
+                sum = wave_inclusive_sum64(sum);
+                if (lane == 63u) blk_sum[k] = sum;
+            }
+            __syncthreads();
+            if (wave == 0u) {  // the value before every listed block's first
+                const uint64_t own = lane < listed ? blk_sum[lane] : 0ull;
+                const uint64_t upto = wave_inclusive_sum64(own);
+                if (lane < listed) blk_sum[lane] = s.acc + upto - own;
+                if (lane == 63u) stand_acc = s.acc + upto;
+            }
+            __syncthreads();
+            for (uint32_t k = wave; k < listed; k += 4u) {
+                const uint32_t len = blk_len[k];
+                const uint64_t min_delta = blk_min[k];
+                uint64_t *dst = s.out + 1ull + blk_first[k];
+                uint64_t before = blk_sum[k];
+                for (uint32_t base = 0; base < len; base += 64u) {
+                    const uint32_t v = base + lane;
+                    const uint64_t value = before + wave_inclusive_sum64(v < len ? term_of(k, v, min_delta) : 0ull);
+                    if (v < len) dst[v] = value;
+                    before = lane_value64(value, 63u);
+                }
+            }
+            s.pos = stand[1], s.remaining = stand[2], s.done = stand[3], s.acc = stand_acc;
+            if (s.remaining == 0u) {
+                report(0);
+                return;
+            }
+            __syncthreads();  // the chunk and the lists are read no more
+        }
+    }
+    if (wave != 0u) return;
+    status = delta_blocks(s, lane, tbl_start, tbl_bits);
+    report(status);
 }
 
 }  // namespace pq2
@@ -1646,7 +1813,7 @@ extern "C" hipError_t pq2_launch_bitunpack64(const void *d_packed, uint32_t pack
 
 extern "C" hipError_t pq2_launch_delta(const void *pages, uint32_t n_pages, void *results, hipStream_t stream) {
     if (n_pages == 0) return hipSuccess;
-    hipLaunchKernelGGL(pq2::delta_kernel, dim3(n_pages), dim3(64), 0, stream, (const pq2::DeltaPage *)pages, n_pages,
+    hipLaunchKernelGGL(pq2::delta_kernel, dim3(n_pages), dim3(256), 0, stream, (const pq2::DeltaPage *)pages, n_pages,
                        (pq2::DeltaResult *)results);
     return hipGetLastError();
 }

@@ -142,7 +142,10 @@ def test_reference_round_trips(ctx, kats):
         assert (delta_bitpacked.Decoder.try_new(delta_bitpacked.encode(v), ctx).collect() == v).all()
 
 
-SHAPES = [(128, 4), (128, 1), (128, 16), (256, 8), (1024, 4), (8192, 128), (1280, 160), (128 * 75, 75 * 2), (640, 5)]
+# the first four are also what the cut and corrupted streams below are made of; blocks of at most 512 values in at
+# most 16 mini-blocks take the kernel's chunked path, the others its general one
+SHAPES = [(128, 4), (128, 1), (128, 16), (256, 8), (1024, 4), (8192, 128), (1280, 160), (128 * 75, 75 * 2), (640, 5),
+          (512, 16), (512, 4), (384, 16), (384, 3), (512, 32)]
 
 
 @pytest.mark.parametrize("block_size,num_mini_blocks", SHAPES)

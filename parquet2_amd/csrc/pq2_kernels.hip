@@ -1549,28 +1549,53 @@ __device__ int32_t delta_blocks(DeltaStream &s, uint32_t lane, uint32_t *tbl_sta
 }
 
 // One workgroup of four waves per stream.  Streams of the usual shape (blocks of at most 512 values in at most 16
-// mini-blocks) go chunk by chunk: the workgroup loads 8 KiB of the stream into LDS -- the only time these bytes
-// are read from memory --, wave 0 walks the block headers inside the chunk (a chain of LDS reads instead of one
-// of memory round trips) and lists every block that lies in the chunk whole and is well-formed, the four waves
-// sum the deltas of the listed blocks, a prefix sum over the block sums gives every block its first value, and
-// the waves extract the deltas once more and store the values.  Where the walk lists nothing -- a block that is
-// cut, malformed or absurd -- and for every other shape of stream, wave 0 goes on alone with delta_blocks from
-// that block on, which also decides the stream's status: the chunked path accepts only what delta_blocks accepts.
-constexpr uint32_t kDeltaChunk = 8192;   // bytes of the stream in LDS
-constexpr uint32_t kDeltaListed = 64;    // blocks listed per chunk
-constexpr uint32_t kDeltaMinis = 16;     // mini-blocks per block on the chunked path
-constexpr uint32_t kDeltaBlockMost = 512;  // values per block on the chunked path (10 + 16 + 512 * 8 bytes < chunk)
+// mini-blocks) go chunk by chunk through two LDS buffers.  Wave 0, the walker, loads 8 KiB of the stream into a
+// buffer -- the only time these bytes are read from memory --, walks the block headers inside it (a chain of LDS
+// reads instead of one of memory round trips) and lists every block that lies in the chunk whole and is
+// well-formed; then it goes on to the next chunk in the other buffer.  Waves 1..3, the expanders, follow one chunk
+// behind: they share out the listed blocks, sum every block's deltas, wait for each other, each takes a prefix sum
+// over the block sums (which gives every block its first value, and the chunk's last value), and they extract
+// the deltas once more and store the values.  Where the walk lists nothing -- a block that is cut, malformed or
+// absurd -- and for every other shape of stream, wave 0 goes on alone with delta_blocks from that block on, which
+// also decides the stream's status: the chunked path accepts only what delta_blocks accepts.
+//
+// The waves of a workgroup are resident together, so every wait below ends: the walker waits for expanders that
+// have all they need, the expanders for a walker that always advances or says that it has stopped; the waits are
+// bounded all the same (status PQ2_DEVICE_ERROR).
+#ifndef PQ2_DELTA_CHUNK
+#define PQ2_DELTA_CHUNK 8192
+#endif
+#ifndef PQ2_DELTA_LISTED
+#define PQ2_DELTA_LISTED 32
+#endif
+constexpr uint32_t kDeltaChunk = PQ2_DELTA_CHUNK;    // bytes of the stream per LDS buffer (a multiple of 1024)
+constexpr uint32_t kDeltaListed = PQ2_DELTA_LISTED;  // blocks listed per chunk (at most 64)
+constexpr uint32_t kDeltaMinis = 16;                 // mini-blocks per block on the chunked path
+// values per block on the chunked path: a block (10 + 16 + 8 bytes per value at most) fits a chunk from any start
+constexpr uint32_t kDeltaBlockMost = kDeltaChunk / 16u;
+static_assert(10u + kDeltaMinis + kDeltaBlockMost * 8u + 15u <= kDeltaChunk && kDeltaListed <= 64u, "delta chunk");
+constexpr uint32_t kDeltaExpanders = 3;
+
+struct DeltaLists {  // what the walker says about one chunk
+    uint64_t blk_min[kDeltaListed];                      // min_delta
+    uint64_t blk_sum[kDeltaListed];                      // (by the expanders) the sum of the block's deltas
+    uint32_t blk_len[kDeltaListed];                      // values
+    uint32_t blk_first[kDeltaListed];                    // index of the first one among the stream's deltas
+    uint16_t mini_start[kDeltaListed * kDeltaMinis];     // byte offset in the chunk
+    uint8_t mini_bits[kDeltaListed * kDeltaMinis];
+    uint32_t listed;  // blocks; 0: the walker has stopped here and takes the rest by itself
+    uint32_t last;    // the stream ends with this chunk
+};
 
 __global__ __launch_bounds__(256) void delta_kernel(const DeltaPage *__restrict__ pages, uint32_t n_pages,
                                                     DeltaResult *__restrict__ results) {
-    __shared__ __attribute__((aligned(16))) uint8_t chunk[kDeltaChunk + 32];
-    __shared__ uint16_t mini_start[kDeltaListed * kDeltaMinis];  // byte offset in the chunk
-    __shared__ uint8_t mini_bits[kDeltaListed * kDeltaMinis];
-    __shared__ uint64_t blk_min[kDeltaListed], blk_sum[kDeltaListed];  // blk_sum: the block's sum, then the value before its first
-    __shared__ uint32_t blk_len[kDeltaListed], blk_first[kDeltaListed];
+    __shared__ __attribute__((aligned(16))) uint8_t chunks[2][kDeltaChunk + 32];
+    __shared__ DeltaLists lists[2];
     __shared__ uint32_t tbl_start[64], tbl_bits[64];
-    __shared__ uint32_t stand[4];  // listed blocks; pos, remaining, done behind them
-    __shared__ uint64_t stand_acc;
+    __shared__ uint32_t walked;                       // chunks whose lists are complete
+    __shared__ uint32_t summed;                       // sum phases finished, over all expanders and chunks
+    __shared__ uint32_t expanded[kDeltaExpanders];    // chunks every expander is done with
+    __shared__ uint64_t acc_after;                    // the last value of the chunks expander 0 is done with
 
     const uint32_t page = blockIdx.x;
     if (page >= n_pages) return;
@@ -1597,34 +1622,52 @@ __global__ __launch_bounds__(256) void delta_kernel(const DeltaPage *__restrict_
     const bool chunked = s.block_size_small != 0u && s.block_size_small <= kDeltaBlockMost &&
                          s.num_mini_blocks <= kDeltaMinis && per_mini32 != 0u;
     if (chunked) {
-        const bool minis_pow2 = (per_mini32 & (per_mini32 - 1u)) == 0u;
-        const uint32_t mini_shift = (uint32_t)__builtin_ctz(per_mini32);
-        const uint32_t block_most = (uint32_t)s.block_most;
-        const uint32_t minis = (uint32_t)s.num_mini_blocks;
-        if (threadIdx.x < 2u) *(u32x4 *)(chunk + kDeltaChunk + threadIdx.x * 16u) = u32x4{0u, 0u, 0u, 0u};
-        for (;;) {
-            const uint32_t chunk_a = s.pos & ~15u;
-            const uint32_t chunk_hi = chunk_a + kDeltaChunk;
-            {
-                const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(s.rsrc, chunk_a + threadIdx.x * 16u, 0, 0);
-                const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(s.rsrc, chunk_a + 4096u + threadIdx.x * 16u, 0, 0);
-                *(u32x4 *)(chunk + threadIdx.x * 16u) = a;
-                *(u32x4 *)(chunk + 4096u + threadIdx.x * 16u) = b;
+        if (threadIdx.x < 4u) *(u32x4 *)(chunks[threadIdx.x >> 1] + kDeltaChunk + (threadIdx.x & 1u) * 16u) = u32x4{0u, 0u, 0u, 0u};
+        if (threadIdx.x == 0u) walked = 0u, summed = 0u, expanded[0] = 0u, expanded[1] = 0u, expanded[2] = 0u;
+        __syncthreads();
+        // waits until *word >= want; false if that never comes
+        auto wait_for = [&](const uint32_t *word, uint32_t want) -> bool {
+            for (uint32_t polls = 0; polls < kMaxPolls; ++polls) {
+                if (__hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= want) return true;
+                __builtin_amdgcn_s_sleep(2);
             }
-            __syncthreads();
-            if (wave == 0u) {
+            if (lane == 0u) results[page].status = 6;  // PQ2_DEVICE_ERROR; never seen
+            return false;
+        };
+        if (wave == 0u) {
+            // ---- the walker ----
+            const uint32_t block_most = (uint32_t)s.block_most;
+            const uint32_t minis = (uint32_t)s.num_mini_blocks;
+            for (uint32_t c = 0;; ++c) {
+                uint8_t *const chunk = chunks[c & 1u];
+                DeltaLists &ls = lists[c & 1u];
+                if (c >= 2u)  // the buffer's chunk before has been expanded
+                    for (uint32_t e = 0; e < kDeltaExpanders; ++e)
+                        if (!wait_for(&expanded[e], c - 1u)) return;
+                const uint32_t chunk_a = s.pos & ~15u;
+                const uint32_t chunk_hi = chunk_a + kDeltaChunk;
+                {
+                    constexpr uint32_t kPieces = kDeltaChunk / 1024u;
+                    u32x4 piece[kPieces];
+#pragma unroll
+                    for (uint32_t i = 0; i < kPieces; ++i)
+                        piece[i] = __builtin_amdgcn_raw_buffer_load_b128(s.rsrc, chunk_a + i * 1024u + lane * 16u, 0, 0);
+#pragma unroll
+                    for (uint32_t i = 0; i < kPieces; ++i) *(u32x4 *)(chunk + i * 1024u + lane * 16u) = piece[i];
+                }
+                wave_sync();
                 // Block::try_new and advance_miniblock as in delta_blocks, out of the chunk; anything but a
                 // well-formed block that lies in the chunk whole ends the list
-                uint32_t listed = 0u, pos = s.pos, remaining = s.remaining, done = s.done;
-                while (remaining != 0u && listed < kDeltaListed) {
-                    if (!(pos + 64u <= chunk_hi || s.end <= chunk_hi)) break;
-                    const uint32_t a = pos + lane;
+                uint32_t listed = 0u;
+                while (s.remaining != 0u && listed < kDeltaListed) {
+                    if (!(s.pos + 64u <= chunk_hi || s.end <= chunk_hi)) break;
+                    const uint32_t a = s.pos + lane;
                     const uint32_t window = a < s.end ? chunk[a - chunk_a] : 0x100u;
                     const Varint md = varint_at(window, 0u);
                     if (md.panics) break;
-                    const uint32_t widths_at = pos + md.used;
+                    const uint32_t widths_at = s.pos + md.used;
                     if (minis > s.end - widths_at) break;
-                    const uint32_t block_len = remaining < block_most ? remaining : block_most;
+                    const uint32_t block_len = s.remaining < block_most ? s.remaining : block_most;
                     const uint32_t needed = (block_len - 1u) / per_mini32 + 1u;
                     const uint32_t at = widths_at + minis;
                     // (the shuffle by all lanes: a lane that is switched off hands nothing over)
@@ -1636,71 +1679,99 @@ __global__ __launch_bounds__(256) void delta_kernel(const DeltaPage *__restrict_
                     const uint32_t total = __builtin_amdgcn_readlane(upto, 63);
                     if (at + total > chunk_hi) break;
                     if (lane < kDeltaMinis) {
-                        mini_start[listed * kDeltaMinis + lane] = (uint16_t)(at + upto - length - chunk_a);
-                        mini_bits[listed * kDeltaMinis + lane] = (uint8_t)bits;
+                        ls.mini_start[listed * kDeltaMinis + lane] = (uint16_t)(at + upto - length - chunk_a);
+                        ls.mini_bits[listed * kDeltaMinis + lane] = (uint8_t)bits;
                     }
                     if (lane == 0u) {
-                        blk_min[listed] = zigzag(md.value);
-                        blk_len[listed] = block_len;
-                        blk_first[listed] = done;
+                        ls.blk_min[listed] = zigzag(md.value);
+                        ls.blk_len[listed] = block_len;
+                        ls.blk_first[listed] = s.done;
                     }
-                    pos = at + total;
-                    done += block_len;
-                    remaining -= block_len;
+                    s.pos = at + total;
+                    s.done += block_len;
+                    s.remaining -= block_len;
                     ++listed;
                 }
-                if (lane == 0u) stand[0] = listed, stand[1] = pos, stand[2] = remaining, stand[3] = done;
-            }
-            __syncthreads();
-            const uint32_t listed = stand[0];
-            if (listed == 0u) break;
-            // min_delta + the packed value v of listed block k
-            auto term_of = [&](uint32_t k, uint32_t v, uint64_t min_delta) -> uint64_t {
-                const uint32_t mini = minis_pow2 ? v >> mini_shift : v / per_mini32;
-                const uint32_t w = mini_bits[k * kDeltaMinis + mini];
-                const uint32_t bit = (uint32_t)mini_start[k * kDeltaMinis + mini] * 8u + (v - mini * per_mini32) * w;
-                const uint32_t *src = (const uint32_t *)(chunk + ((bit >> 5) << 2));
-                const uint32_t sh = bit & 31u;
-                const uint32_t x0 = src[0], x1 = src[1], x2 = w > 32u ? src[2] : 0u;
-                const uint64_t field = ((uint64_t)__builtin_amdgcn_alignbit(x2, x1, sh) << 32) |
-                                       __builtin_amdgcn_alignbit(x1, x0, sh);
-                const uint64_t mask = w == 0u ? 0ull : (~0ull >> (64u - w));
-                return min_delta + (field & mask);
-            };
-            for (uint32_t k = wave; k < listed; k += 4u) {  // the sum of every listed block
-                const uint32_t len = blk_len[k];
-                const uint64_t min_delta = blk_min[k];
-                uint64_t sum = 0ull;
-                for (uint32_t v = lane; v < len; v += 64u) sum += term_of(k, v, min_delta);
-                sum = wave_inclusive_sum64(sum);
-                if (lane == 63u) blk_sum[k] = sum;
-            }
-            __syncthreads();
-            if (wave == 0u) {  // the value before every listed block's first
-                const uint64_t own = lane < listed ? blk_sum[lane] : 0ull;
-                const uint64_t upto = wave_inclusive_sum64(own);
-                if (lane < listed) blk_sum[lane] = s.acc + upto - own;
-                if (lane == 63u) stand_acc = s.acc + upto;
-            }
-            __syncthreads();
-            for (uint32_t k = wave; k < listed; k += 4u) {
-                const uint32_t len = blk_len[k];
-                const uint64_t min_delta = blk_min[k];
-                uint64_t *dst = s.out + 1ull + blk_first[k];
-                uint64_t before = blk_sum[k];
-                for (uint32_t base = 0; base < len; base += 64u) {
-                    const uint32_t v = base + lane;
-                    const uint64_t value = before + wave_inclusive_sum64(v < len ? term_of(k, v, min_delta) : 0ull);
-                    if (v < len) dst[v] = value;
-                    before = lane_value64(value, 63u);
+                const bool last = s.remaining == 0u;
+                if (lane == 0u) {
+                    ls.listed = listed, ls.last = last ? 1u : 0u;
+                    // release: the lists and the chunk are visible to whoever sees the new number
+                    __hip_atomic_store(&walked, c + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                if (listed == 0u) {
+                    // the rest is for delta_blocks, from the last value of the chunks before
+                    if (c != 0u) {
+                        if (!wait_for(&expanded[0], c)) return;
+                        s.acc = acc_after;
+                    }
+                    break;
+                }
+                if (last) {
+                    report(0);
+                    return;
                 }
             }
-            s.pos = stand[1], s.remaining = stand[2], s.done = stand[3], s.acc = stand_acc;
-            if (s.remaining == 0u) {
-                report(0);
-                return;
+        } else {
+            // ---- the expanders ----
+            const uint32_t e = wave - 1u;
+            const bool minis_pow2 = (per_mini32 & (per_mini32 - 1u)) == 0u;
+            const uint32_t mini_shift = (uint32_t)__builtin_ctz(per_mini32);
+            uint64_t acc = s.acc;  // the last value before the chunk
+            for (uint32_t c = 0;; ++c) {
+                const uint8_t *const chunk = chunks[c & 1u];
+                DeltaLists &ls = lists[c & 1u];
+                if (!wait_for(&walked, c + 1u)) return;
+                const uint32_t listed = ls.listed;
+                if (listed == 0u) return;
+                // min_delta + the packed value v of listed block k
+                auto term_of = [&](uint32_t k, uint32_t v, uint64_t min_delta) -> uint64_t {
+                    const uint32_t mini = minis_pow2 ? v >> mini_shift : v / per_mini32;
+                    const uint32_t w = ls.mini_bits[k * kDeltaMinis + mini];
+                    const uint32_t bit = (uint32_t)ls.mini_start[k * kDeltaMinis + mini] * 8u + (v - mini * per_mini32) * w;
+                    const uint32_t *src = (const uint32_t *)(chunk + ((bit >> 5) << 2));
+                    const uint32_t sh = bit & 31u;
+                    const uint32_t x0 = src[0], x1 = src[1], x2 = w > 32u ? src[2] : 0u;
+                    const uint64_t field = ((uint64_t)__builtin_amdgcn_alignbit(x2, x1, sh) << 32) |
+                                           __builtin_amdgcn_alignbit(x1, x0, sh);
+                    const uint64_t mask = w == 0u ? 0ull : (~0ull >> (64u - w));
+                    return min_delta + (field & mask);
+                };
+                for (uint32_t k = e; k < listed; k += kDeltaExpanders) {  // the sums of this wave's blocks
+                    const uint32_t len = ls.blk_len[k];
+                    const uint64_t min_delta = ls.blk_min[k];
+                    uint64_t sum = 0ull;
+                    for (uint32_t v = lane; v < len; v += 64u) sum += term_of(k, v, min_delta);
+                    sum = wave_inclusive_sum64(sum);
+                    if (lane == 63u) ls.blk_sum[k] = sum;
+                }
+                // all three have stored their sums (release / acquire through the counter)
+                if (lane == 0u) __hip_atomic_fetch_add(&summed, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (!wait_for(&summed, kDeltaExpanders * (c + 1u))) return;
+                // the value before every listed block's first, lane k for block k
+                const uint64_t own = lane < listed ? ls.blk_sum[lane] : 0ull;
+                const uint64_t upto = wave_inclusive_sum64(own);
+                const uint64_t before_block = acc + upto - own;
+                acc += lane_value64(upto, 63u);
+                for (uint32_t k = e; k < listed; k += kDeltaExpanders) {
+                    const uint32_t len = ls.blk_len[k];
+                    const uint64_t min_delta = ls.blk_min[k];
+                    uint64_t *dst = s.out + 1ull + ls.blk_first[k];
+                    uint64_t before = lane_value64(before_block, k);
+                    for (uint32_t base = 0; base < len; base += 64u) {
+                        const uint32_t v = base + lane;
+                        const uint64_t value = before + wave_inclusive_sum64(v < len ? term_of(k, v, min_delta) : 0ull);
+                        if (v < len) dst[v] = value;
+                        before = lane_value64(value, 63u);
+                    }
+                }
+                const bool last = ls.last != 0u;
+                if (lane == 0u) {
+                    if (e == 0u) acc_after = acc;
+                    // release: this wave reads the buffer no more (and acc_after is in place)
+                    __hip_atomic_store(&expanded[e], c + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                if (last) return;
             }
-            __syncthreads();  // the chunk and the lists are read no more
         }
     }
     if (wave != 0u) return;

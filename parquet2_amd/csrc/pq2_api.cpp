@@ -25,11 +25,12 @@ hipError_t pq2_launch_parse(const void *pages, uint32_t n_pages, void *resume, u
                             int32_t *status, void *state, uint32_t round, uint32_t max_bits, hipStream_t stream);
 hipError_t pq2_launch_expand(const void *pages, const uint32_t *tile_page, uint32_t tile_start, uint32_t n_tiles,
                              const void *resume, const uint32_t *run_pos, uint32_t round, uint32_t max_bits,
-                             hipStream_t stream);
+                             const uint32_t *tile_mask, hipStream_t stream);
 hipError_t pq2_launch_bitunpack(const void *d_packed, uint32_t packed_len, uint32_t num_bits, uint32_t length,
                                 uint32_t *d_out, hipStream_t stream);
 hipError_t pq2_launch_decode(const void *pages, uint32_t n_pages, void *resume, uint32_t *run_pos, int32_t *status,
-                             void *state, uint32_t *cu_tickets, uint32_t max_bits, hipStream_t stream);
+                             void *state, uint32_t *cu_tickets, uint32_t max_bits, const uint32_t *tile_mask,
+                             hipStream_t stream);
 uint32_t pq2_cu_ticket_bytes();
 hipError_t pq2_launch_gather(const void *pages, uint32_t n_pages, uint32_t n_tiles, uint32_t value_words,
                              uint64_t max_dict_bytes, int32_t *status, hipStream_t stream);
@@ -106,6 +107,13 @@ struct DeltaResult {  // must match pq2::DeltaResult
     uint64_t num_values;
 };
 static_assert(sizeof(DeltaResult) == 16, "DeltaResult layout");
+
+// What pq2_decode_selected_batch_device adds to a batch: one bit per tile of every page that says whether the
+// tile holds a selected row (`at[i]`: the page's first word in `words`, plus one; 0: every tile).
+struct TileMask {
+    std::vector<uint32_t> words;
+    std::vector<uint32_t> at;
+};
 
 // What pq2_decode_raw_pages_v1_device adds to a batch: front_kernel patches the uploaded stream descriptors.
 struct FrontJob {
@@ -247,7 +255,7 @@ int32_t upload_block(pq2_ctx *ctx, size_t bytes, hipStream_t stream) {
 // them and enqueues parse + expand on `stream`.
 int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const pq2_page_desc *descs, uint64_t n_pages,
                       uint32_t *d_out, uint64_t out_values, hipStream_t stream, const FrontJob *front = nullptr,
-                      uint32_t min_max_bits = 0) {
+                      uint32_t min_max_bits = 0, const TileMask *mask = nullptr) {
     if (n_pages > 0x7fffffffull) return fail(ctx, PQ2_INVALID_PARAMETER, "too many pages in one batch");
     if (n_pages > 0 && !descs) return fail(ctx, PQ2_INVALID_PARAMETER, "descs is NULL");
     // the device-side metadata and the Resume table are shared by consecutive batches: stream order
@@ -259,7 +267,10 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
     if (n_pages == 0) return PQ2_OK;
     ctx->busy = true;
 
-    const size_t meta_bytes = n_pages * sizeof(PageDev);
+    // the page descriptors and, behind them, the tile mask of a selected-rows batch
+    const size_t pages_bytes = n_pages * sizeof(PageDev);
+    const size_t mask_bytes = mask ? mask->words.size() * sizeof(uint32_t) : 0;
+    const size_t meta_bytes = pages_bytes + mask_bytes;
     int32_t st = reserve_pinned(ctx, meta_bytes);
     if (st) return st;
     if (ctx->meta_in_flight) {  // the previous batch's upload still reads the pinned block
@@ -267,6 +278,7 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
         ctx->meta_in_flight = false;
     }
     PageDev *pages = static_cast<PageDev *>(ctx->h_meta);
+    if (mask_bytes) std::memcpy(static_cast<uint8_t *>(ctx->h_meta) + pages_bytes, mask->words.data(), mask_bytes);
 
     uint64_t tiles = 0, run_entries = 0;
     uint32_t max_bits = 0;  // over the pages that are decoded
@@ -289,7 +301,7 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
             p.num_values = 0;
         }
         const uint64_t page_tiles = (uint64_t(p.num_values) + kTileValues - 1) / kTileValues;
-        p.reserved = 0;
+        p.reserved = mask ? mask->at[i] : 0;
         if (p.num_values > 0) max_bits = std::max(max_bits, p.num_bits);
         // header-position list: a run that yields values takes >= 2 stream bytes and >= 1 value; + the closing
         // entry, + the 64 entries a wave may read past the last one, rounded to whole 64-entry stores
@@ -357,6 +369,8 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
     if (front)  // the streams' addresses, lengths and index widths come out of the page buffers on the device
         PQ2_HIP(ctx, pq2_launch_front(ctx->d_meta.ptr, front->d_raw, front->n_pages, front->d_front_status, stream));
     max_bits = std::max(max_bits, min_max_bits);
+    const uint32_t *d_tile_mask =
+        mask_bytes ? reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(ctx->d_meta.ptr) + pages_bytes) : nullptr;
 
     const PageDev *d_pages = static_cast<const PageDev *>(ctx->d_meta.ptr);
     uint32_t *d_tile_page = static_cast<uint32_t *>(ctx->d_tile_page.ptr);
@@ -405,7 +419,7 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
         if ((st = stamped(true, stream, [&] {
                  return pq2_launch_decode(d_pages, static_cast<uint32_t>(n_pages), ctx->d_resume.ptr, d_run_pos, d_status,
                                           ctx->d_state.ptr, static_cast<uint32_t *>(ctx->d_tickets.ptr), max_bits,
-                                          stream);
+                                          d_tile_mask, stream);
              })))
             return st;
         rounds = 0;
@@ -423,7 +437,7 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
         if ((st = stamped(true, es[r & 1u], [&] {
                  return pq2_launch_expand(d_pages, d_tile_page, static_cast<uint32_t>(round_start[r]),
                                           static_cast<uint32_t>(round_start[r + 1] - round_start[r]),
-                                          ctx->d_resume.ptr, d_run_pos, r, max_bits, es[r & 1u]);
+                                          ctx->d_resume.ptr, d_run_pos, r, max_bits, d_tile_mask, es[r & 1u]);
              })))
             return st;
     }
@@ -706,9 +720,15 @@ int32_t pq2_decode_selected_batch_device(pq2_ctx *ctx, const void *d_in, uint64_
     // every page decoded in full into the context's buffer, 16-byte aligned
     std::vector<pq2_page_desc> full(descs, descs + n_pages);
     std::vector<SelectPiece> pieces;
+    TileMask mask;  // the tiles no interval touches are not expanded
+    mask.at.assign(n_pages, 0);
     uint64_t at = 0;
     for (uint64_t i = 0; i < n_pages; ++i) {
         full[i].out_off = at;
+        if (descs[i].num_values <= PQ2_MAX_PAGE_VALUES && mask.words.size() < 0x7fffffffull) {
+            mask.at[i] = static_cast<uint32_t>(mask.words.size()) + 1u;
+            mask.words.resize(mask.words.size() + ((descs[i].num_values + kTileValues - 1) / kTileValues + 31) / 32, 0u);
+        }
         if (interval_offsets[i] > interval_offsets[i + 1])
             return fail(ctx, PQ2_INVALID_PARAMETER, "interval_offsets must ascend");
         if (interval_offsets[i] < interval_offsets[i + 1] && !intervals)
@@ -722,6 +742,9 @@ int32_t pq2_decode_selected_batch_device(pq2_ctx *ctx, const void *d_in, uint64_
                             "intervals must hold at least one row, ascend without overlap and end inside the page");
             current = iv.start + iv.length;
             selected += iv.length;
+            if (mask.at[i] != 0)
+                for (uint64_t t = iv.start / kTileValues; t <= (iv.start + iv.length - 1) / kTileValues; ++t)
+                    mask.words[mask.at[i] - 1u + (t >> 5)] |= 1u << (t & 31u);
         }
         if (descs[i].out_off > out_values || selected > out_values - descs[i].out_off)
             return fail(ctx, PQ2_INVALID_PARAMETER, "selected rows outside the output buffer");
@@ -731,7 +754,7 @@ int32_t pq2_decode_selected_batch_device(pq2_ctx *ctx, const void *d_in, uint64_
     if (ctx->busy && ctx->last_stream != stream) PQ2_HIP(ctx, hipStreamSynchronize(ctx->last_stream));
     if ((st = reserve(ctx, ctx->d_indices, std::max<uint64_t>(at, 1) * sizeof(uint32_t)))) return st;
     uint32_t *d_full = static_cast<uint32_t *>(ctx->d_indices.ptr);
-    if ((st = enqueue_batch(ctx, d_in, in_bytes, full.data(), n_pages, d_full, at, stream))) return st;
+    if ((st = enqueue_batch(ctx, d_in, in_bytes, full.data(), n_pages, d_full, at, stream, nullptr, 0, &mask))) return st;
     for (uint64_t i = 0; i < n_pages; ++i) {
         if (ctx->host_status[i] != PQ2_OK) continue;
         uint64_t dst = descs[i].out_off;

@@ -822,6 +822,13 @@ __device__ __forceinline__ void expand_page_tile(const PageDev &pg, const u32x4 
     }
 }
 
+// Selected rows: a page whose `reserved` is not 0 has one bit per tile from word `reserved - 1` of `tile_mask` on;
+// tiles whose bit is clear hold no selected row and are not expanded (their values are never read).
+__device__ __forceinline__ bool tile_wanted(const PageDev &pg, const uint32_t *__restrict__ tile_mask, uint32_t t) {
+    if (pg.reserved == 0u || tile_mask == nullptr) return true;
+    return ((tile_mask[pg.reserved - 1u + (t >> 5)] >> (t & 31u)) & 1u) != 0u;
+}
+
 #ifndef PQ2_EXPAND_WAVES
 #define PQ2_EXPAND_WAVES 5
 #endif
@@ -832,7 +839,8 @@ __global__ __launch_bounds__(256, PQ2_EXPAND_WAVES) void expand_kernel(const Pag
                                                        const Resume *__restrict__ resume,
                                                        const uint32_t *__restrict__ run_pos,
                                                        uint32_t tile_start, uint32_t tile_end, uint32_t round,
-                                                       uint32_t win_bytes, uint32_t win_bit_mask) {
+                                                       uint32_t win_bytes, uint32_t win_bit_mask,
+                                                       const uint32_t *__restrict__ tile_mask) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -845,6 +853,7 @@ __global__ __launch_bounds__(256, PQ2_EXPAND_WAVES) void expand_kernel(const Pag
     const PageDev pg = pages[tile_page[tile]];
     const uint32_t tile_first = (pg.round_first(round) + (tile - pg.round_base(round))) * kTileValues;
     if (tile_first >= pg.num_values) return;
+    if (!tile_wanted(pg, tile_mask, tile_first / kTileValues)) return;
 
     uint2 *tbl = (uint2 *)(lds + 4u * win_bytes + 32u) + wave * (kTableRuns + 2);
     uint32_t *cidx = (uint32_t *)(lds + 4u * win_bytes + 32u + 4u * (kTableRuns + 2) * 8u) + wave * kChunkSlots;
@@ -898,7 +907,8 @@ __global__ __launch_bounds__(256, 4) void decode_kernel(const PageDev *__restric
                                                          Resume *__restrict__ resume, uint32_t *__restrict__ run_pos,
                                                          int32_t *__restrict__ status, ParseState *__restrict__ state,
                                                          uint32_t *__restrict__ cu_tickets, uint32_t win_bytes,
-                                                         uint32_t win_bit_mask) {
+                                                         uint32_t win_bit_mask,
+                                                         const uint32_t *__restrict__ tile_mask) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -942,6 +952,11 @@ __global__ __launch_bounds__(256, 4) void decode_kernel(const PageDev *__restric
     const uint32_t n = pg.num_values;
     const uint32_t n_tiles = (n + kTileValues - 1u) / kTileValues;
     for (uint32_t t = e; t < n_tiles; t += kDecodeExpanders) {
+        if (!tile_wanted(pg, tile_mask, t)) {  // done without a look: the walk counts on this number only
+            if (lane == 0)
+                __hip_atomic_store(parsed + 1u + e, t / kDecodeExpanders + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            continue;
+        }
         const uint32_t need = min((t + 1u) * kTileValues, n);
         uint32_t polls = 0, covered;
         while ((covered = __hip_atomic_load(parsed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < need) {
@@ -1799,7 +1814,7 @@ extern "C" hipError_t pq2_launch_parse(const void *pages, uint32_t n_pages, void
 // a page in the batch: the stream window of a wave is sized for a whole tile of bit-packed values of that width.
 extern "C" hipError_t pq2_launch_expand(const void *pages, const uint32_t *tile_page, uint32_t tile_start,
                                         uint32_t n_tiles, const void *resume, const uint32_t *run_pos, uint32_t round,
-                                        uint32_t max_bits, hipStream_t stream) {
+                                        uint32_t max_bits, const uint32_t *tile_mask, hipStream_t stream) {
     if (n_tiles == 0) return hipSuccess;
     uint32_t win_bytes = (pq2::kTileValues / 8u) * (max_bits ? max_bits : 1u) + 256u;
     if (win_bytes < 2048u) win_bytes = 2048u;
@@ -1812,7 +1827,7 @@ extern "C" hipError_t pq2_launch_expand(const void *pages, const uint32_t *tile_
     const uint32_t lds_bytes = 4u * win_bytes + 32u + 4u * (pq2::kTableRuns + 2u) * 8u + 4u * pq2::kChunkSlots * 4u;
     hipLaunchKernelGGL(pq2::expand_kernel, dim3((n_tiles + 3u) / 4u), dim3(256), lds_bytes, stream,
                        (const pq2::PageDev *)pages, tile_page, (const pq2::Resume *)resume, run_pos, tile_start,
-                       tile_start + n_tiles, round, win_bytes, pow2 * 8u - 1u);
+                       tile_start + n_tiles, round, win_bytes, pow2 * 8u - 1u, tile_mask);
     return hipGetLastError();
 }
 
@@ -1821,7 +1836,7 @@ extern "C" uint32_t pq2_cu_ticket_bytes() { return pq2::kCuTickets * 4u; }
 
 extern "C" hipError_t pq2_launch_decode(const void *pages, uint32_t n_pages, void *resume, uint32_t *run_pos,
                                         int32_t *status, void *state, uint32_t *cu_tickets, uint32_t max_bits,
-                                        hipStream_t stream) {
+                                        const uint32_t *tile_mask, hipStream_t stream) {
     if (n_pages == 0) return hipSuccess;
     constexpr uint32_t kFixed = pq2::kWin + 32u +
                                 pq2::kDecodeExpanders * ((pq2::kTableRuns + 2u) * 8u + pq2::kChunkSlots * 4u) + 64u;
@@ -1838,11 +1853,11 @@ extern "C" hipError_t pq2_launch_decode(const void *pages, uint32_t n_pages, voi
     if (max_bits > 16u)
         hipLaunchKernelGGL(pq2::decode_kernel<true>, dim3(n_pages), dim3(256), lds_bytes, stream,
                            (const pq2::PageDev *)pages, n_pages, (pq2::Resume *)resume, run_pos, status,
-                           (pq2::ParseState *)state, cu_tickets, win_bytes, pow2 * 8u - 1u);
+                           (pq2::ParseState *)state, cu_tickets, win_bytes, pow2 * 8u - 1u, tile_mask);
     else
         hipLaunchKernelGGL(pq2::decode_kernel<false>, dim3(n_pages), dim3(256), lds_bytes, stream,
                            (const pq2::PageDev *)pages, n_pages, (pq2::Resume *)resume, run_pos, status,
-                           (pq2::ParseState *)state, cu_tickets, win_bytes, pow2 * 8u - 1u);
+                           (pq2::ParseState *)state, cu_tickets, win_bytes, pow2 * 8u - 1u, tile_mask);
     return hipGetLastError();
 }
 

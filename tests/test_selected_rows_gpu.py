@@ -94,6 +94,37 @@ def test_against_the_host_iterator(ctx, oracle):
     assert int((got != 0x5A5A5A5A).sum()) <= total  # nothing is written between the pages' selections
 
 
+def test_few_rows_of_large_pages(ctx, oracle):
+    """Most tiles of 4096 values hold no selected row and are not expanded; the selected rows still come out right
+    (intervals at tile boundaries, in the first and the last tile, across several tiles)."""
+    rng = np.random.default_rng(17)
+    pages, selections = [], []
+    for p in range(70):
+        w = (3, 12, 20)[p % 3]
+        n = int(rng.integers(30000, 90000))
+        stream, _ = synth.dict_page(synth.seed_for(2, 300 + p), n, w, 15.0, 70.0)
+        pages.append((stream, w, n))
+        kind = p % 5
+        if kind == 0:
+            sel = [(0, 1), (n - 1, 1)]
+        elif kind == 1:
+            sel = [(4095, 2), (3 * 4096, 4096), (5 * 4096 + 7, 1)]
+        elif kind == 2:
+            sel = [(int(rng.integers(0, n - 10000)), 9000)]
+        elif kind == 3:
+            sel = []
+        else:
+            sel = [(4096, 1), (n - 5000, 4000)]
+        selections.append(sel)
+    results, status, _ = run(ctx, pages, selections)
+    assert (status == OK).all()
+    for (stream, w, n), sel, res in zip(pages, selections, results):
+        st, values = oracle.hybrid_rle_decode(stream, w, n)
+        assert st == OK
+        expected = np.concatenate([values[a:a + b] for a, b in sel]) if sel else values[:0]
+        assert (res == expected).all()
+
+
 def test_interval_lists_the_reference_cannot_take(ctx):
     stream = np.frombuffer(encode_u32(np.arange(64, dtype=np.uint32), 6), dtype=np.uint8)
     for sel in ([(5, 0)], [(10, 5), (12, 3)], [(10, 5), (3, 2)], [(60, 5)], [(65, 1)]):

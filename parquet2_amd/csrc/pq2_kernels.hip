@@ -1111,9 +1111,10 @@ __global__ __launch_bounds__(256) void gather_kernel(const GatherPage *__restric
 // (deserialize_levels, tests/it/read/utils.rs:52-66, over an OptionalDictionary
 // page, tests/it/read/primitive.rs:104-110): row r is valid where its level
 // equals the maximum, and the k-th valid row takes the dictionary value of the
-// page's k-th index.  One workgroup per page walks the page's rows 1024 at a
-// time (four consecutive rows per thread), carrying the count of valid rows: a
-// prefix sum over the lanes of a wave, the four wave totals through LDS.
+// page's k-th index.  One workgroup per page walks the page's rows 4096 at a
+// time (four quads of four consecutive rows per thread, all of their loads in
+// flight together), carrying the count of valid rows: a prefix sum over the
+// lanes of a wave, the wave totals through LDS, one barrier per step.
 // ---------------------------------------------------------------------------
 struct OptionalPage {  // must match the host's
     uint64_t level_addr;  // decoded levels (u32), one per row; 16-byte aligned
@@ -1127,7 +1128,9 @@ struct OptionalPage {  // must match the host's
 template <int kWords>
 __global__ __launch_bounds__(256) void optional_kernel(const OptionalPage *__restrict__ pages, uint32_t n_pages,
                                                        int32_t *__restrict__ status) {
-    __shared__ uint32_t wave_total[2][4];
+    constexpr uint32_t kQuads = 4;                    // quads of rows per thread and step
+    constexpr uint32_t kStepRows = 1024u * kQuads;    // rows of a page per step: quad q of thread t = rows q * 1024 + 4 t ...
+    __shared__ uint32_t wave_total[2][kQuads][4];
     const uint32_t page = blockIdx.x;
     if (page >= n_pages) return;
     const OptionalPage pg = pages[page];
@@ -1157,75 +1160,91 @@ __global__ __launch_bounds__(256) void optional_kernel(const OptionalPage *__res
     };
     // whole quads of rows are written with one store each where the page's values and validity bytes are aligned
     const bool aligned = ((pg.out_addr & 15u) | (pg.validity_addr & 3u)) == 0u;
-    u32x4 lv_next = load_levels(4u * threadIdx.x);
-    for (uint32_t base = 0; base < pg.rows; base += 1024u, flip ^= 1u) {
-        const uint32_t r0 = base + 4u * threadIdx.x;
-        const u32x4 lv = lv_next;
-        lv_next = load_levels(r0 + 1024u);  // the next step's levels are on their way while this step works
-        const uint32_t l4[4] = {lv.x, lv.y, lv.z, lv.w};
-        bool v[4];
-        uint32_t c = 0;
+    u32x4 lv_next[kQuads];
 #pragma unroll
-        for (uint32_t k = 0; k < 4u; ++k) {
-            v[k] = r0 + k < pg.rows && l4[k] == pg.max_level;
-            c += v[k] ? 1u : 0u;
-        }
-        const uint32_t incl = wave_inclusive_sum(c);
-        if (lane == 63u) wave_total[flip][wave] = incl;
-        __syncthreads();  // (the other buffer is written in the next step, this one again only after that step's barrier)
-        uint32_t below = 0, all = 0;
+    for (uint32_t q = 0; q < kQuads; ++q) lv_next[q] = load_levels(q * 1024u + 4u * threadIdx.x);
+    for (uint32_t base = 0; base < pg.rows; base += kStepRows, flip ^= 1u) {
+        uint32_t r0[kQuads], c[kQuads], incl[kQuads];
+        bool v[kQuads][4];
 #pragma unroll
-        for (uint32_t k = 0; k < 4u; ++k) {
-            const uint32_t t = wave_total[flip][k];
-            below += k < wave ? t : 0u;
-            all += t;
-        }
-        uint32_t rank = used + below + incl - c;
-        bool present[4];
-        uint32_t j[4];
-#pragma unroll
-        for (uint32_t k = 0; k < 4u; ++k) {
-            present[k] = v[k] && rank < pg.idx_values;  // behind the last index: values.next() is None
-            j[k] = 0;
-            if (present[k]) j[k] = idx[rank];
-            rank += v[k] ? 1u : 0u;
-        }
-        uint32_t val[4][kWords];
-#pragma unroll
-        for (uint32_t k = 0; k < 4u; ++k) {
-            const bool ok = j[k] < pg.dict_len;
-            bad |= present[k] && !ok;
-#pragma unroll
-            for (int w = 0; w < kWords; ++w) val[k][w] = 0u;
-            if (present[k] && ok) {
-#pragma unroll
-                for (int w = 0; w < kWords; ++w) val[k][w] = dict[(size_t)j[k] * kWords + w];
-            }
-        }
-        if (aligned && r0 + 3u < pg.rows) {
-            uint32_t flat[4 * kWords];
-#pragma unroll
-            for (uint32_t k = 0; k < 4u; ++k)
-#pragma unroll
-                for (int w = 0; w < kWords; ++w) flat[k * kWords + w] = val[k][w];
-#pragma unroll
-            for (int w = 0; w < kWords; ++w) {
-                const u32x4 o = {flat[4 * w], flat[4 * w + 1], flat[4 * w + 2], flat[4 * w + 3]};
-                *((out_u32x4 *)out + (size_t)(r0 >> 2) * kWords + w) = o;
-            }
-            *(__attribute__((address_space(1))) uint32_t *)(validity + r0) =
-                (present[0] ? 1u : 0u) | (present[1] ? 0x100u : 0u) | (present[2] ? 0x10000u : 0u) |
-                (present[3] ? 0x1000000u : 0u);
-        } else {
+        for (uint32_t q = 0; q < kQuads; ++q) {
+            r0[q] = base + q * 1024u + 4u * threadIdx.x;
+            const u32x4 lv = lv_next[q];
+            lv_next[q] = load_levels(r0[q] + kStepRows);  // the next step's levels are on their way while this step works
+            const uint32_t l4[4] = {lv.x, lv.y, lv.z, lv.w};
+            c[q] = 0;
 #pragma unroll
             for (uint32_t k = 0; k < 4u; ++k) {
-                if (r0 + k >= pg.rows) break;
+                v[q][k] = r0[q] + k < pg.rows && l4[k] == pg.max_level;
+                c[q] += v[q][k] ? 1u : 0u;
+            }
+            incl[q] = wave_inclusive_sum(c[q]);
+            if (lane == 63u) wave_total[flip][q][wave] = incl[q];
+        }
+        __syncthreads();  // (the other buffer is written in the next step, this one again only after that step's barrier)
+        bool present[kQuads][4];
+        uint32_t j[kQuads][4];
+        uint32_t before = used;  // valid rows before the quads q of all threads
 #pragma unroll
-                for (int w = 0; w < kWords; ++w) out[(size_t)(r0 + k) * kWords + w] = val[k][w];
-                validity[r0 + k] = present[k] ? 1 : 0;
+        for (uint32_t q = 0; q < kQuads; ++q) {
+            uint32_t below = 0, all = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k) {
+                const uint32_t t = wave_total[flip][q][k];
+                below += k < wave ? t : 0u;
+                all += t;
+            }
+            uint32_t rank = before + below + incl[q] - c[q];
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k) {
+                present[q][k] = v[q][k] && rank < pg.idx_values;  // behind the last index: values.next() is None
+                j[q][k] = 0;
+                if (present[q][k]) j[q][k] = idx[rank];
+                rank += v[q][k] ? 1u : 0u;
+            }
+            before += all;
+        }
+        used = before;
+        uint32_t val[kQuads][4][kWords];
+#pragma unroll
+        for (uint32_t q = 0; q < kQuads; ++q)
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k) {
+                const bool ok = j[q][k] < pg.dict_len;
+                bad |= present[q][k] && !ok;
+#pragma unroll
+                for (int w = 0; w < kWords; ++w) val[q][k][w] = 0u;
+                if (present[q][k] && ok) {
+#pragma unroll
+                    for (int w = 0; w < kWords; ++w) val[q][k][w] = dict[(size_t)j[q][k] * kWords + w];
+                }
+            }
+#pragma unroll
+        for (uint32_t q = 0; q < kQuads; ++q) {
+            if (aligned && r0[q] + 3u < pg.rows) {
+                uint32_t flat[4 * kWords];
+#pragma unroll
+                for (uint32_t k = 0; k < 4u; ++k)
+#pragma unroll
+                    for (int w = 0; w < kWords; ++w) flat[k * kWords + w] = val[q][k][w];
+#pragma unroll
+                for (int w = 0; w < kWords; ++w) {
+                    const u32x4 o = {flat[4 * w], flat[4 * w + 1], flat[4 * w + 2], flat[4 * w + 3]};
+                    *((out_u32x4 *)out + (size_t)(r0[q] >> 2) * kWords + w) = o;
+                }
+                *(__attribute__((address_space(1))) uint32_t *)(validity + r0[q]) =
+                    (present[q][0] ? 1u : 0u) | (present[q][1] ? 0x100u : 0u) | (present[q][2] ? 0x10000u : 0u) |
+                    (present[q][3] ? 0x1000000u : 0u);
+            } else {
+#pragma unroll
+                for (uint32_t k = 0; k < 4u; ++k) {
+                    if (r0[q] + k >= pg.rows) break;
+#pragma unroll
+                    for (int w = 0; w < kWords; ++w) out[(size_t)(r0[q] + k) * kWords + w] = val[q][k][w];
+                    validity[r0[q] + k] = present[q][k] ? 1 : 0;
+                }
             }
         }
-        used += all;
     }
     const int any_bad = __syncthreads_or(bad ? 1 : 0);
     if (threadIdx.x == 0 && status[page] == 0) {

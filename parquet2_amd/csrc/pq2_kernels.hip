@@ -1755,7 +1755,7 @@ __global__ __launch_bounds__(256) void delta_kernel(const DeltaPage *__restrict_
                 const uint8_t *const chunk = chunks[c & 1u];
                 DeltaLists &ls = lists[c & 1u];
                 if (!wait_for(&walked, c + 1u)) return;
-                const uint32_t listed = ls.listed;
+                const uint32_t listed = __builtin_amdgcn_readfirstlane(ls.listed);  // (the same for every lane: into a scalar register)
                 if (listed == 0u) return;
                 // min_delta + the packed value v of listed block k
                 auto term_of = [&](uint32_t k, uint32_t v, uint64_t min_delta) -> uint64_t {
@@ -1771,7 +1771,7 @@ __global__ __launch_bounds__(256) void delta_kernel(const DeltaPage *__restrict_
                     return min_delta + (field & mask);
                 };
                 for (uint32_t k = e; k < listed; k += kDeltaExpanders) {  // the sums of this wave's blocks
-                    const uint32_t len = ls.blk_len[k];
+                    const uint32_t len = __builtin_amdgcn_readfirstlane(ls.blk_len[k]);
                     const uint64_t min_delta = ls.blk_min[k];
                     uint64_t sum = 0ull;
                     for (uint32_t v = lane; v < len; v += 64u) sum += term_of(k, v, min_delta);
@@ -1787,9 +1787,9 @@ __global__ __launch_bounds__(256) void delta_kernel(const DeltaPage *__restrict_
                 const uint64_t before_block = acc + upto - own;
                 acc += lane_value64(upto, 63u);
                 for (uint32_t k = e; k < listed; k += kDeltaExpanders) {
-                    const uint32_t len = ls.blk_len[k];
+                    const uint32_t len = __builtin_amdgcn_readfirstlane(ls.blk_len[k]);
                     const uint64_t min_delta = ls.blk_min[k];
-                    uint64_t *dst = s.out + 1ull + ls.blk_first[k];
+                    uint64_t *dst = s.out + 1ull + __builtin_amdgcn_readfirstlane(ls.blk_first[k]);
                     uint64_t before = lane_value64(before_block, k);
                     for (uint32_t base = 0; base < len; base += 64u) {
                         const uint32_t v = base + lane;
@@ -1798,7 +1798,7 @@ __global__ __launch_bounds__(256) void delta_kernel(const DeltaPage *__restrict_
                         before = lane_value64(value, 63u);
                     }
                 }
-                const bool last = ls.last != 0u;
+                const bool last = __builtin_amdgcn_readfirstlane(ls.last) != 0u;
                 if (lane == 0u) {
                     if (e == 0u) acc_after = acc;
                     // release: this wave reads the buffer no more (and acc_after is in place)

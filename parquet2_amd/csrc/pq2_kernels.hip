@@ -1751,6 +1751,7 @@ __global__ __launch_bounds__(256) void delta_kernel(const DeltaPage *__restrict_
             const bool minis_pow2 = (per_mini32 & (per_mini32 - 1u)) == 0u;
             const uint32_t mini_shift = (uint32_t)__builtin_ctz(per_mini32);
             uint64_t acc = s.acc;  // the last value before the chunk
+            const bool small_blocks = s.block_most <= 128ull;
             for (uint32_t c = 0;; ++c) {
                 const uint8_t *const chunk = chunks[c & 1u];
                 DeltaLists &ls = lists[c & 1u];
@@ -1770,13 +1771,34 @@ __global__ __launch_bounds__(256) void delta_kernel(const DeltaPage *__restrict_
                     const uint64_t mask = w == 0u ? 0ull : (~0ull >> (64u - w));
                     return min_delta + (field & mask);
                 };
-                for (uint32_t k = e; k < listed; k += kDeltaExpanders) {  // the sums of this wave's blocks
-                    const uint32_t len = __builtin_amdgcn_readfirstlane(ls.blk_len[k]);
-                    const uint64_t min_delta = ls.blk_min[k];
-                    uint64_t sum = 0ull;
-                    for (uint32_t v = lane; v < len; v += 64u) sum += term_of(k, v, min_delta);
-                    sum = wave_inclusive_sum64(sum);
-                    if (lane == 63u) ls.blk_sum[k] = sum;
+                // Blocks of at most 128 values (the usual size) are extracted once: the running sums inside the
+                // block stay in registers until the block's first value is known.
+                constexpr uint32_t kKept = (kDeltaListed + kDeltaExpanders - 1u) / kDeltaExpanders;  // blocks per wave
+                uint64_t kept[kKept][2];
+                if (small_blocks) {
+#pragma unroll
+                    for (uint32_t i = 0; i < kKept; ++i) {
+                        const uint32_t k = e + i * kDeltaExpanders;
+                        kept[i][0] = kept[i][1] = 0ull;
+                        if (k < listed) {
+                            const uint32_t len = __builtin_amdgcn_readfirstlane(ls.blk_len[k]);
+                            const uint64_t min_delta = ls.blk_min[k];
+                            const uint64_t term0 = lane < len ? term_of(k, lane, min_delta) : 0ull;
+                            const uint64_t term1 = lane + 64u < len ? term_of(k, lane + 64u, min_delta) : 0ull;
+                            kept[i][0] = wave_inclusive_sum64(term0);
+                            kept[i][1] = lane_value64(kept[i][0], 63u) + wave_inclusive_sum64(term1);
+                            if (lane == 63u) ls.blk_sum[k] = kept[i][1];
+                        }
+                    }
+                } else {
+                    for (uint32_t k = e; k < listed; k += kDeltaExpanders) {  // the sums of this wave's blocks
+                        const uint32_t len = __builtin_amdgcn_readfirstlane(ls.blk_len[k]);
+                        const uint64_t min_delta = ls.blk_min[k];
+                        uint64_t sum = 0ull;
+                        for (uint32_t v = lane; v < len; v += 64u) sum += term_of(k, v, min_delta);
+                        sum = wave_inclusive_sum64(sum);
+                        if (lane == 63u) ls.blk_sum[k] = sum;
+                    }
                 }
                 // all three have stored their sums (release / acquire through the counter)
                 if (lane == 0u) __hip_atomic_fetch_add(&summed, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1786,6 +1808,19 @@ __global__ __launch_bounds__(256) void delta_kernel(const DeltaPage *__restrict_
                 const uint64_t upto = wave_inclusive_sum64(own);
                 const uint64_t before_block = acc + upto - own;
                 acc += lane_value64(upto, 63u);
+                if (small_blocks) {
+#pragma unroll
+                    for (uint32_t i = 0; i < kKept; ++i) {
+                        const uint32_t k = e + i * kDeltaExpanders;
+                        if (k < listed) {
+                            const uint32_t len = __builtin_amdgcn_readfirstlane(ls.blk_len[k]);
+                            uint64_t *dst = s.out + 1ull + __builtin_amdgcn_readfirstlane(ls.blk_first[k]);
+                            const uint64_t before = lane_value64(before_block, k);
+                            if (lane < len) dst[lane] = before + kept[i][0];
+                            if (lane + 64u < len) dst[lane + 64u] = before + kept[i][1];
+                        }
+                    }
+                } else
                 for (uint32_t k = e; k < listed; k += kDeltaExpanders) {
                     const uint32_t len = __builtin_amdgcn_readfirstlane(ls.blk_len[k]);
                     const uint64_t min_delta = ls.blk_min[k];

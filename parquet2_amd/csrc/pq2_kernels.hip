@@ -1702,7 +1702,8 @@ __global__ __launch_bounds__(256) void delta_kernel(const DeltaPage *__restrict_
                     const uint32_t widths_at = s.pos + md.used;
                     if (minis > s.end - widths_at) break;
                     const uint32_t block_len = s.remaining < block_most ? s.remaining : block_most;
-                    const uint32_t needed = (block_len - 1u) / per_mini32 + 1u;
+                    // (a whole block opens all of its mini-blocks: the division is for the stream's last block)
+                    const uint32_t needed = block_len == block_most ? minis : (block_len - 1u) / per_mini32 + 1u;
                     const uint32_t at = widths_at + minis;
                     // (the shuffle by all lanes: a lane that is switched off hands nothing over)
                     const uint32_t behind = (uint32_t)__shfl((int)window, (int)((md.used + lane) & 63u)) & 0xffu;

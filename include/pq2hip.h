@@ -13,6 +13,14 @@
  *  - plain pointers and sizes only; the caller owns every buffer it passes;
  *  - `d_*` arguments are device pointers on the context's GPU, `h_*` / bare
  *    pointers are host pointers;
+ *  - device input buffers (`d_in`, `d_buf`, `d_packed`): the kernels read a
+ *    stream in aligned 16-byte pieces, so they touch up to 15 bytes in front
+ *    of a stream's first byte and up to 15 bytes behind its last one (never
+ *    beyond the 16-byte line that holds that byte).  Those bytes have to be
+ *    readable: allocate the buffer 16-byte aligned (hipMalloc does) and 16 bytes
+ *    larger than `in_bytes`, or keep every stream inside 16-byte-aligned bounds of
+ *    a larger allocation.  Their contents do not matter.  The host entry points
+ *    pad their own staging copies;
  *  - every function returns a pq2 status (0 = OK); decode entry points also
  *    fill one status per page so that one malformed page does not poison a
  *    batch;
@@ -235,7 +243,9 @@ typedef struct pq2_raw_page {
  * without values (utils.rs:18); PQ2_INVALID_PARAMETER for an index width above
  * max_index_bits; else the statuses of the repetition, definition and index
  * streams in this order.  The outputs of a page with a non-OK status are
- * unspecified. */
+ * unspecified.  `status` is required (n_pages entries) and the call waits for
+ * completion: the statuses of the page front end are kept in scratch that the
+ * next call on the context reuses, so this entry point has no enqueue-only form. */
 int32_t pq2_decode_raw_pages_v1_device(pq2_ctx *ctx, const void *d_buf, uint64_t buf_bytes, const pq2_raw_page *pages,
                                        uint64_t n_pages, uint32_t max_index_bits, uint32_t *d_rep, uint32_t *d_def,
                                        uint32_t *d_idx, uint64_t out_values, int32_t *status, void *stream);

@@ -215,10 +215,10 @@ int32_t reserve_pinned(pq2_ctx *ctx, size_t bytes) {
         PQ2_HIP(ctx, hipEventSynchronize(ctx->meta_copied));
         ctx->meta_in_flight = false;
     }
+    const size_t cap = (std::max(bytes, ctx->h_meta_cap * 2) + 4095) & ~size_t(4095);  // geometric growth
     if (ctx->h_meta) PQ2_HIP(ctx, hipHostFree(ctx->h_meta));
     ctx->h_meta = nullptr;
     ctx->h_meta_cap = 0;
-    size_t cap = (std::max(bytes, ctx->h_meta_cap * 2) + 4095) & ~size_t(4095);
     PQ2_HIP(ctx, hipHostMalloc(&ctx->h_meta, cap, hipHostMallocDefault));
     ctx->h_meta_cap = cap;
     return PQ2_OK;
@@ -233,10 +233,10 @@ int32_t stage_block(pq2_ctx *ctx, size_t bytes, size_t device_bytes) {
         ctx->gather_in_flight = false;
     }
     if (bytes > ctx->h_gather_cap) {
+        const size_t cap = (std::max(bytes, ctx->h_gather_cap * 2) + 4095) & ~size_t(4095);  // geometric growth
         if (ctx->h_gather) PQ2_HIP(ctx, hipHostFree(ctx->h_gather));
         ctx->h_gather = nullptr;
         ctx->h_gather_cap = 0;
-        const size_t cap = (std::max(bytes, ctx->h_gather_cap * 2) + 4095) & ~size_t(4095);
         PQ2_HIP(ctx, hipHostMalloc(&ctx->h_gather, cap, hipHostMallocDefault));
         ctx->h_gather_cap = cap;
     }
@@ -261,11 +261,14 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
     // the device-side metadata and the Resume table are shared by consecutive batches: stream order
     // protects them on one stream, a change of stream needs the previous batch to have finished
     if (ctx->busy && ctx->last_stream != stream) PQ2_HIP(ctx, hipStreamSynchronize(ctx->last_stream));
+    // Until this batch is accepted and enqueued there is no batch whose statuses could be fetched: a call that
+    // fails below leaves pq2_fetch_status nothing to report (n_pages = 0) instead of an earlier batch's array.
+    ctx->last_n_pages = 0;
     ctx->host_status.assign(n_pages, PQ2_OK);
-    ctx->last_n_pages = n_pages;
-    ctx->last_stream = stream;
-    if (n_pages == 0) return PQ2_OK;
-    ctx->busy = true;
+    if (n_pages == 0) {
+        ctx->last_stream = stream;
+        return PQ2_OK;
+    }
 
     // the page descriptors and, behind them, the tile mask of a selected-rows batch
     const size_t pages_bytes = n_pages * sizeof(PageDev);
@@ -363,6 +366,8 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
     if (!per_page && (st = reserve(ctx, ctx->d_tile_page, std::max<uint64_t>(tiles, 1) * sizeof(uint32_t)))) return st;
     if ((st = reserve(ctx, ctx->d_run_pos, std::max<uint64_t>(run_entries, 1) * sizeof(uint32_t)))) return st;
 
+    ctx->last_stream = stream;  // from here on work of this batch may be running on `stream`
+    ctx->busy = true;
     PQ2_HIP(ctx, hipMemcpyAsync(ctx->d_meta.ptr, ctx->h_meta, meta_bytes, hipMemcpyHostToDevice, stream));
     PQ2_HIP(ctx, hipEventRecord(ctx->meta_copied, stream));
     ctx->meta_in_flight = true;
@@ -450,6 +455,7 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
         }
     }
     if (ctx->profiling) ++ctx->stamped_batches;
+    ctx->last_n_pages = n_pages;
     return PQ2_OK;
 }
 
@@ -790,6 +796,8 @@ int32_t pq2_decode_raw_pages_v1_device(pq2_ctx *ctx, const void *d_buf, uint64_t
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (n_pages > 0x2aaaaaaaull) return fail(ctx, PQ2_INVALID_PARAMETER, "too many pages in one batch");
     if (n_pages > 0 && !pages) return fail(ctx, PQ2_INVALID_PARAMETER, "pages is NULL");
+    // the statuses of the page front end live in scratch that the next call reuses: they are delivered with this call
+    if (n_pages > 0 && !status) return fail(ctx, PQ2_INVALID_PARAMETER, "status is NULL");
     if (max_index_bits == 0 || max_index_bits > 32) max_index_bits = 32;
     uint32_t *const outs[3] = {d_rep, d_def, d_idx};
     for (uint32_t *o : outs)
@@ -835,7 +843,7 @@ int32_t pq2_decode_raw_pages_v1_device(pq2_ctx *ctx, const void *d_buf, uint64_t
     if ((st = enqueue_batch(ctx, nullptr, ~0ull, streams.data(), 3 * n_pages, nullptr, ~0ull >> 3, stream,
                             n_pages ? &job : nullptr, max_index_bits)))
         return st;
-    if (!status || n_pages == 0) return PQ2_OK;
+    if (n_pages == 0) return PQ2_OK;
     std::vector<int32_t> of_streams(3 * n_pages), of_front(n_pages);
     if ((st = fetch_status(ctx, of_streams.data(), 3 * n_pages))) return st;  // waits for the batch
     PQ2_HIP(ctx, hipMemcpy(of_front.data(), job.d_front_status, n_pages * sizeof(int32_t), hipMemcpyDeviceToHost));

@@ -62,9 +62,11 @@ constexpr int kHalfPieces = (int)(kHalf / 1024u);  // dwordx4 loads of the wave 
 // would not reach cannot fail the page).
 // ---------------------------------------------------------------------------
 // The chase loop of parse_kernel (see there).  HI_READ / HI_PARK: the instructions that move the second four
-// bytes behind a header into the record, or nothing.
+// bytes behind a header into the record, or nothing.  The statement uses M0 (the lane select of v_writelane) and
+// narrows EXEC to lane 0; it puts both back before it ends, so neither is named as clobbered.
 #define PQ2_CHASE(HI_READ, HI_PARK) \
 asm volatile( \
+                "s_mov_b32 %[m0_kept], m0\n\t" \
                 "s_mov_b64 %[exec_all], exec\n\t" \
                 "s_mov_b64 exec, 1\n\t" \
                 "s_sub_u32 %[m], %[m], 64\n\t" \
@@ -100,10 +102,12 @@ asm volatile( \
                 "s_cbranch_scc1 1b\n\t" \
                 "s_waitcnt lgkmcnt(0)\n\t" \
                 "s_mov_b64 exec, %[exec_all]\n\t" \
+                "s_mov_b32 m0, %[m0_kept]\n\t" \
                 "s_add_u32 %[m], %[m], 64" \
                 : [pos] "+s"(pos), [m] "+s"(m), [r_pos] "+v"(r_pos), [r_lo] "+v"(r_lo), [r_hi] "+v"(r_hi), \
                   [lo] "=&s"(lo), [hi] "=&s"(hi), [groups] "=&s"(groups), [t] "=&s"(t), [bytes] "=&s"(bytes), \
-                  [nm1] "=&s"(nm1), [chk] "=&s"(chk), [addr] "=&v"(addr), [exec_all] "=&s"(exec_all) \
+                  [nm1] "=&s"(nm1), [chk] "=&s"(chk), [addr] "=&v"(addr), [exec_all] "=&s"(exec_all), \
+                  [m0_kept] "=&s"(m0_kept) \
                 : [w] "s"(w), [rb] "s"(rb), [limit] "s"(min(end - 1u, win_lo + kWin - 9u)), [voff] "v"(voff), \
                   [voff1] "v"(voff + 1u) \
                 : "v2", "v3", "scc", "memory");
@@ -262,6 +266,7 @@ __device__ __forceinline__ void parse_page(const PageDev &pg, const uint32_t pag
             // minus 64 inside so that the 64th increment sets the carry.
             uint32_t lo, hi, groups, t, bytes, nm1, chk, addr;  // nm1: the next header's position minus one
             uint64_t exec_all;
+            uint32_t m0_kept;
             const uint32_t voff = lds_base - win_lo;
             // the bytes behind the header's first four are only needed for RLE values of more than two bytes
             if constexpr (kWide) {
@@ -281,13 +286,18 @@ __device__ __forceinline__ void parse_page(const PageDev &pg, const uint32_t pag
                 const uint32_t e_hi = __builtin_amdgcn_readfirstlane(run.count);
                 const uint32_t e_info = __builtin_amdgcn_readfirstlane(run.kind == kRle ? run.value : run.payload);
                 // v_writelane_b32 ignores EXEC; it may read one scalar register only, so the lane goes through M0
+                // (kept and put back: the compiler does not know that the statement writes it)
+                uint32_t m0_was;
                 asm volatile(
+                    "s_mov_b32 %[m0_was], m0\n\t"
                     "s_mov_b32 m0, %[m]\n\t"
                     "v_writelane_b32 %[r_pos], %[pos], m0\n\t"
                     "v_writelane_b32 %[r_lo], %[e_lo], m0\n\t"
                     "v_writelane_b32 %[r_hi], %[e_hi], m0\n\t"
-                    "v_writelane_b32 %[r_info], %[e_info], m0"
-                    : [r_pos] "+v"(r_pos), [r_lo] "+v"(r_lo), [r_hi] "+v"(r_hi), [r_info] "+v"(r_info)
+                    "v_writelane_b32 %[r_info], %[e_info], m0\n\t"
+                    "s_mov_b32 m0, %[m0_was]"
+                    : [r_pos] "+v"(r_pos), [r_lo] "+v"(r_lo), [r_hi] "+v"(r_hi), [r_info] "+v"(r_info),
+                      [m0_was] "=&s"(m0_was)
                     : [m] "s"(m), [pos] "s"(pos), [e_lo] "s"(e_lo), [e_hi] "s"(e_hi), [e_info] "s"(e_info));
                 ++m;
                 if (run.kind >= kEnd) {

@@ -376,6 +376,18 @@ def test_bad_descriptors_are_rejected(ctx):
         ctx.decode_batch_host(data, descs, 5)
     out, status = ctx.decode_batch_host(data, np.zeros(0, dtype=PAGE_DESC_DTYPE), 0)
     assert out.size == 0 and status.size == 0
+    # a rejected batch leaves no statuses to fetch: not those of the batch before it either
+    import torch
+
+    good = np.zeros(1, dtype=PAGE_DESC_DTYPE)
+    good[0] = (0, 10, 3, 5, 0)
+    d_in = torch.zeros(80, dtype=torch.uint8, device="cuda")
+    d_out = torch.zeros(64, dtype=torch.int32, device="cuda")
+    assert ctx.decode_batch_device(d_in.data_ptr(), 64, good, d_out.data_ptr(), 64).tolist() == [OK]
+    with pytest.raises(InvalidParameter):
+        ctx.decode_batch_device(d_in.data_ptr(), 64, descs, d_out.data_ptr(), 5, want_status=False)
+    with pytest.raises(InvalidParameter):
+        ctx.fetch_status(1)
 
 
 def test_idempotent_and_checksum_at_scale(ctx, oracle):

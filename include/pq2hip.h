@@ -129,6 +129,44 @@ int32_t pq2_fetch_status(pq2_ctx *ctx, int32_t *status, uint64_t n_pages);
 int32_t pq2_decode_batch_host(pq2_ctx *ctx, const void *h_in, uint64_t in_bytes, const pq2_page_desc *descs,
                               uint64_t n_pages, uint32_t *h_out, uint64_t out_values, int32_t *status);
 
+/* ---- the batch decode without allocation ------------------------------------- */
+
+/* No counterpart in the reference.  For callers that cannot allocate: code
+ * under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc.  The decode of pq2_decode_batch_device, with everything its
+ * kernels need beyond the inputs and outputs (device page descriptors, parse
+ * state, the table of block starts, the header-position lists) inside one
+ * fixed array of the library's code object, which every GPU the library runs
+ * on holds until the process ends (about 34 MiB).  The call allocates nothing
+ * and frees nothing; it only enqueues three kernels on `stream` and returns.
+ *
+ * Differences from pq2_decode_batch_device:
+ *  - no context: `device_id` names the GPU;
+ *  - `d_descs` and `d_status` are DEVICE arrays of n_pages entries (the caller's
+ *    own buffers; d_descs 8-byte aligned): the descriptors are checked on the
+ *    device.  A descriptor the host entry point would reject (stream or output
+ *    outside the buffers, num_bits > 32 or > max_bits) fails its own page with
+ *    PQ2_INVALID_PARAMETER instead of the call; the other pages are decoded;
+ *  - `max_bits`: an upper bound of the pages' bit widths (0 = unknown: 32 is
+ *    assumed, at the price of larger LDS windows);
+ *  - limits: n_pages <= PQ2_NOALLOC_MAX_PAGES and out_values <=
+ *    PQ2_NOALLOC_MAX_VALUES, else the call returns PQ2_WOULD_OVER_ALLOCATE and
+ *    enqueues nothing; and the header-position lists of the batch, sized as
+ *    sum over pages of (min(num_values, in_len / 2) + 128) rounded down to a
+ *    multiple of 64, must fit PQ2_NOALLOC_MAX_RUN_ENTRIES: that sum is known
+ *    on the device only, and a batch beyond it gets PQ2_WOULD_OVER_ALLOCATE as
+ *    the status of every page and decodes nothing;
+ *  - every call on one GPU uses that GPU's one array: calls on one stream
+ *    follow each other safely, calls that overlap on one GPU (two streams, two
+ *    threads) race.  Nothing in the array has to be cleared between calls.
+ * The statuses are complete when the work on `stream` is. */
+#define PQ2_NOALLOC_MAX_PAGES 4096u
+#define PQ2_NOALLOC_MAX_VALUES (1ull << 26)
+#define PQ2_NOALLOC_MAX_RUN_ENTRIES (8ull << 20)
+int32_t pq2_decode_batch_device_noalloc(int32_t device_id, const void *d_in, uint64_t in_bytes,
+                                        const pq2_page_desc *d_descs, uint64_t n_pages, uint32_t max_bits,
+                                        uint32_t *d_out, uint64_t out_values, int32_t *d_status, void *stream);
+
 /* ---- dictionary pages: indices -> values ---------------------------------- */
 
 /* Where a page's dictionary lies inside the dictionary buffer: `dict_len`

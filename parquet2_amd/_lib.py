@@ -68,6 +68,8 @@ SIGNATURES = {
     "pq2_decode_batch_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p,
                                              C.c_uint64, C.c_void_p, C.c_void_p]),
     "pq2_fetch_status": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64]),
+    "pq2_decode_batch_device_noalloc": (C.c_int32, [C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+                                                     C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     "pq2_decode_dict_batch_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p,
                                                   C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p,
                                                   C.c_void_p]),
@@ -348,6 +350,16 @@ def default_context(device_id=0):
     if ctx is None:
         ctx = _DEFAULT_CTX[device_id] = Context(device_id)
     return ctx
+
+
+def decode_batch_device_noalloc(device_id, d_in_ptr, in_bytes, d_descs_ptr, n_pages, max_bits, d_out_ptr, out_values,
+                                d_status_ptr, stream=0):
+    """pq2_decode_batch_device_noalloc: descriptors and statuses are device arrays of the caller; enqueue only."""
+    st = lib().pq2_decode_batch_device_noalloc(device_id, C.c_void_p(d_in_ptr), in_bytes, C.c_void_p(d_descs_ptr),
+                                               n_pages, max_bits, C.c_void_p(d_out_ptr), out_values,
+                                               C.c_void_p(d_status_ptr), C.c_void_p(stream))
+    if st != OK:
+        raise_for_status(st, "pq2_decode_batch_device_noalloc: " + lib().pq2_strerror(st).decode())
 
 
 def partition_pages(descs, n_parts):

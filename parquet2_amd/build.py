@@ -7,7 +7,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIB_DIR, "libpq2hip.so")
-SOURCES = ["pq2_kernels.hip", "pq2_api.cpp", "pq2_host.cpp"]
+SOURCES = ["pq2_kernels.hip", "pq2_noalloc.hip", "pq2_api.cpp", "pq2_host.cpp"]
 DEPS = SOURCES + ["pq2_device.h", os.path.join("..", "..", "include", "pq2hip.h")]
 
 

@@ -42,6 +42,7 @@ hipError_t pq2_launch_optional(const void *pages, uint32_t n_pages, uint32_t val
 hipError_t pq2_launch_bitunpack64(const void *d_packed, uint32_t packed_len, uint32_t num_bits, uint32_t length,
                                   uint64_t *d_out, hipStream_t stream);
 hipError_t pq2_launch_delta(const void *pages, uint32_t n_pages, void *results, hipStream_t stream);
+int32_t pq2_noalloc_setup(int32_t device, uint8_t **out);  // pq2_noalloc.hip
 }
 
 namespace {
@@ -502,6 +503,10 @@ int32_t pq2_ctx_create(int32_t device_id, pq2_ctx **out) {
         delete ctx;
         return PQ2_DEVICE_ERROR;
     }
+    // where this GPU's copy of the fixed working memory of pq2_decode_batch_device_noalloc lies: looked up here so
+    // that a process which creates a context first never does it inside a capture (a GPU number beyond that
+    // table only means the entry point reports it)
+    (void)pq2_noalloc_setup(device_id, nullptr);
     *out = ctx;
     return PQ2_OK;
 }

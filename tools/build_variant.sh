@@ -6,4 +6,4 @@ name=$1; shift
 mkdir -p $root/parquet2_amd/lib/variants
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wall "$@" \
   -o $root/parquet2_amd/lib/variants/libpq2hip_$name.so \
-  $root/parquet2_amd/csrc/pq2_kernels.hip $root/parquet2_amd/csrc/pq2_api.cpp $root/parquet2_amd/csrc/pq2_host.cpp
+  $root/parquet2_amd/csrc/pq2_kernels.hip $root/parquet2_amd/csrc/pq2_noalloc.hip $root/parquet2_amd/csrc/pq2_api.cpp $root/parquet2_amd/csrc/pq2_host.cpp

@@ -1,14 +1,20 @@
-"""Builds libpq2hip.so (HIP kernels for gfx950 + the C ABI) in-tree with hipcc."""
+"""Builds libpq2hip.so (HIP kernels for gfx950 + the C ABI) in-tree with hipcc.
+
+Every source is compiled to an object of its own (in parallel, and only when it or a header changed), then the
+objects are linked: the two large kernel files take minutes each, the rest seconds."""
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
+OBJ_DIR = os.path.join(LIB_DIR, "obj")
 LIB = os.path.join(LIB_DIR, "libpq2hip.so")
-SOURCES = ["pq2_kernels.hip", "pq2_noalloc.hip", "pq2_api.cpp", "pq2_host.cpp"]
-DEPS = SOURCES + ["pq2_device.h", os.path.join("..", "..", "include", "pq2hip.h")]
+SOURCES = ["pq2_kernels.hip", "pq2_ring.hip", "pq2_noalloc.hip", "pq2_api.cpp", "pq2_host.cpp"]
+HEADERS = ["pq2_device.h", os.path.join("..", "..", "include", "pq2hip.h")]
+DEPS = SOURCES + HEADERS
 
 
 def hipcc():
@@ -41,18 +47,42 @@ def build_synth(force=False, verbose=False):
     return SYNTH_LIB
 
 
-def build(force=False, verbose=False, extra_flags=()):
+def build(force=False, verbose=False, extra_flags=(), lib=LIB, obj_dir=OBJ_DIR):
+    """`lib` / `obj_dir` / `extra_flags`: A/B builds (tools/build_variant.sh) next to the product library."""
     build_synth(force, verbose)
-    if not force and up_to_date():
-        return LIB
-    os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-           "-o", LIB] + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES]
+    if not force and lib == LIB and up_to_date():
+        return lib
+    os.makedirs(obj_dir, exist_ok=True)
+    os.makedirs(os.path.dirname(lib), exist_ok=True)
+    newest_header = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall"] + list(extra_flags)
+
+    def compile_one(src):
+        path = os.path.join(CSRC, src)
+        obj = os.path.join(obj_dir, src + ".o")
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(path), newest_header):
+            return obj
+        cmd = [hipcc()] + flags + ["-c", path, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        objs = list(pool.map(compile_one, SOURCES))
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    flags = [a for a in sys.argv[1:] if a.startswith("-D")]
+    name = next((a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--variant=")), None)
+    if name:  # python -m parquet2_amd.build --variant=<name> -DFLAG...: lib/variants/libpq2hip_<name>.so
+        print(build(force=True, verbose=True, extra_flags=flags,
+                    lib=os.path.join(LIB_DIR, "variants", "libpq2hip_%s.so" % name),
+                    obj_dir=os.path.join(LIB_DIR, "obj_" + name)))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True, extra_flags=flags))

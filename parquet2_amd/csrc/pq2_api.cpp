@@ -43,6 +43,9 @@ hipError_t pq2_launch_bitunpack64(const void *d_packed, uint32_t packed_len, uin
                                   uint64_t *d_out, hipStream_t stream);
 hipError_t pq2_launch_delta(const void *pages, uint32_t n_pages, void *results, hipStream_t stream);
 int32_t pq2_noalloc_setup(int32_t device, uint8_t **out);  // pq2_noalloc.hip
+hipError_t pq2_launch_ring(const void *pages, uint32_t n_pages, int32_t *status, uint32_t *cu_tickets, uint32_t max_bits,
+                           const uint32_t *tile_mask, hipStream_t stream);  // pq2_ring.hip
+uint32_t pq2_ring_ticket_bytes();
 }
 
 namespace {
@@ -151,7 +154,10 @@ struct pq2_ctx {
     // expansion of a page side by side (batches with enough pages to fill the GPU that way).  kPerTile:
     // parse_kernel + expand_kernel, one wave per 4096 values, in rounds (few, large pages).  PQ2_MODE=page|tile
     // forces one of them.
-    enum Mode { kAuto, kPerPage, kPerTile } mode = kAuto;
+    // kRing: ring_kernel, one workgroup per page like kPerPage, but the stream is staged once through an LDS ring
+    // that the walking wave fills and all four waves read, and nothing passes through device memory on its way
+    // from the walk to the expansion (PQ2_MODE=ring; what kAuto picks for batches of many pages).
+    enum Mode { kAuto, kPerPage, kPerTile, kRing } mode = kAuto;
     bool one_expand_stream = true;  // the expand launches of a batch follow each other (PQ2_EXPAND_STREAMS=2: they take turns on two streams)
     bool split_given = false;       // PQ2_ROUND_SPLIT was set
     // rounds: parse_kernel of round r + 1 runs on parse_stream while expand_kernel of round r runs on expand_stream
@@ -319,7 +325,8 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
     // enough pages to fill the GPU with one workgroup each: the per-page kernel has every walk running from the
     // start, nothing of a page waits for other pages, and the stream comes out of the cache the second time it is
     // read; fewer pages: the tiles of all pages share the whole GPU
-    const bool per_page = ctx->mode == pq2_ctx::kPerPage || (ctx->mode == pq2_ctx::kAuto && n_pages >= kFusedMinPages);
+    const bool ring = ctx->mode == pq2_ctx::kRing || (ctx->mode == pq2_ctx::kAuto && n_pages >= kFusedMinPages);
+    const bool per_page = ring || ctx->mode == pq2_ctx::kPerPage;
     // tiles are numbered round-major: all tiles of round 0 of all pages, then round 1, ...
     const bool split = !per_page && tiles >= ctx->min_rounded_tiles;
     // Nothing hides the parse of the first part, and the walk of a page takes the same time whatever the batch
@@ -362,10 +369,12 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
 
     if ((st = reserve(ctx, ctx->d_meta, meta_bytes))) return st;
     if ((st = reserve(ctx, ctx->d_status, n_pages * sizeof(int32_t)))) return st;
-    if ((st = reserve(ctx, ctx->d_state, n_pages * kParseStateBytes))) return st;
-    if ((st = reserve(ctx, ctx->d_resume, std::max<uint64_t>(tiles, 1) * kBlocksPerTile * 16))) return st;
-    if (!per_page && (st = reserve(ctx, ctx->d_tile_page, std::max<uint64_t>(tiles, 1) * sizeof(uint32_t)))) return st;
-    if ((st = reserve(ctx, ctx->d_run_pos, std::max<uint64_t>(run_entries, 1) * sizeof(uint32_t)))) return st;
+    if (!ring) {  // what the header walk hands to the expansion through device memory
+        if ((st = reserve(ctx, ctx->d_state, n_pages * kParseStateBytes))) return st;
+        if ((st = reserve(ctx, ctx->d_resume, std::max<uint64_t>(tiles, 1) * kBlocksPerTile * 16))) return st;
+        if (!per_page && (st = reserve(ctx, ctx->d_tile_page, std::max<uint64_t>(tiles, 1) * sizeof(uint32_t)))) return st;
+        if ((st = reserve(ctx, ctx->d_run_pos, std::max<uint64_t>(run_entries, 1) * sizeof(uint32_t)))) return st;
+    }
 
     ctx->last_stream = stream;  // from here on work of this batch may be running on `stream`
     ctx->busy = true;
@@ -419,10 +428,14 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
     };
     if (per_page) {
         if (!ctx->d_tickets.ptr) {
-            if ((st = reserve(ctx, ctx->d_tickets, pq2_cu_ticket_bytes()))) return st;
-            PQ2_HIP(ctx, hipMemsetAsync(ctx->d_tickets.ptr, 0, pq2_cu_ticket_bytes(), stream));
+            const size_t ticket_bytes = std::max(pq2_cu_ticket_bytes(), pq2_ring_ticket_bytes());
+            if ((st = reserve(ctx, ctx->d_tickets, ticket_bytes))) return st;
+            PQ2_HIP(ctx, hipMemsetAsync(ctx->d_tickets.ptr, 0, ticket_bytes, stream));
         }
         if ((st = stamped(true, stream, [&] {
+                 if (ring)
+                     return pq2_launch_ring(d_pages, static_cast<uint32_t>(n_pages), d_status,
+                                            static_cast<uint32_t *>(ctx->d_tickets.ptr), max_bits, d_tile_mask, stream);
                  return pq2_launch_decode(d_pages, static_cast<uint32_t>(n_pages), ctx->d_resume.ptr, d_run_pos, d_status,
                                           ctx->d_state.ptr, static_cast<uint32_t *>(ctx->d_tickets.ptr), max_bits,
                                           d_tile_mask, stream);
@@ -493,6 +506,7 @@ int32_t pq2_ctx_create(int32_t device_id, pq2_ctx **out) {
     if (const char *v = std::getenv("PQ2_MODE")) {
         if (std::strcmp(v, "page") == 0) ctx->mode = pq2_ctx::kPerPage;
         if (std::strcmp(v, "tile") == 0) ctx->mode = pq2_ctx::kPerTile;
+        if (std::strcmp(v, "ring") == 0) ctx->mode = pq2_ctx::kRing;
     }
     if (const char *v = std::getenv("PQ2_ROUND_SPLIT")) {
         double a = 0, b = 0, c = 0;

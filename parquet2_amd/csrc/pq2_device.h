@@ -572,4 +572,89 @@ __device__ __forceinline__ void emit_bp_dispatch(uint32_t w, __amdgpu_buffer_rsr
     }
 }
 
+// ---- the chase loop of the header walk (parse_page in pq2_kernels.hip, ring_walk in pq2_ring.hip) ------------
+// One pass per run: the header at `pos` (already requested from LDS) gives the next header's position, whose
+// 8 bytes are requested at once; (position, bytes) of the current run are parked in lane `m` of r_pos / r_lo /
+// r_hi.  Runs with headers of one or two bytes that end at or before `chase_limit` keep the loop going; it stops
+// behind the record that does not (and behind the 64th).  The caller provides the variables it names: pos, m,
+// r_pos, r_lo, r_hi, lo, hi, groups, t, bytes, nm1, chk, addr, exec_all, m0_kept, w, rb, chase_limit and voff
+// (LDS address of stream byte 0 as far as this stretch of the walk is concerned).  HI_READ / HI_PARK: the instructions that move the second four
+// bytes behind a header into the record, or nothing.  The statement uses M0 (the lane select of v_writelane) and
+// narrows EXEC to lane 0; it puts both back before it ends, so neither is named as clobbered.
+#define PQ2_CHASE(HI_READ, HI_PARK) \
+asm volatile( \
+                "s_mov_b32 %[m0_kept], m0\n\t" \
+                "s_mov_b64 %[exec_all], exec\n\t" \
+                "s_mov_b64 exec, 1\n\t" \
+                "s_sub_u32 %[m], %[m], 64\n\t" \
+                "v_add_u32 %[addr], %[pos], %[voff]\n\t" \
+                "ds_read_b64 v[2:3], %[addr]\n" \
+                "1:\n\t" \
+                "s_waitcnt lgkmcnt(0)\n\t" \
+                "v_readfirstlane_b32 %[lo], v2\n\t" \
+                "s_bfe_u32 %[groups], %[lo], 0x60001\n\t" \
+                "s_lshr_b32 %[t], %[lo], 2\n\t" \
+                "s_and_b32 %[t], %[t], 0x1fc0\n\t" \
+                "s_bitcmp1_b32 %[lo], 7\n\t" \
+                "s_cselect_b32 %[t], %[t], 0\n\t" \
+                "s_or_b32 %[groups], %[groups], %[t]\n\t" \
+                "s_mul_i32 %[bytes], %[groups], %[w]\n\t" \
+                "s_bitcmp1_b32 %[lo], 0\n\t" \
+                "s_cselect_b32 %[bytes], %[bytes], %[rb]\n\t" \
+                "s_bitcmp1_b32 %[lo], 7\n\t" \
+                "s_addc_u32 %[nm1], %[pos], %[bytes]\n\t" \
+                HI_READ \
+                "v_add_u32 %[addr], %[nm1], %[voff1]\n\t" \
+                "ds_read_b64 v[2:3], %[addr]\n\t" \
+                "s_mov_b32 m0, %[m]\n\t" \
+                "v_writelane_b32 %[r_pos], %[pos], m0\n\t" \
+                "v_writelane_b32 %[r_lo], %[lo], m0\n\t" \
+                HI_PARK \
+                "s_add_u32 %[pos], %[nm1], 1\n\t" \
+                "s_andn2_b32 %[t], 0x8080, %[lo]\n\t" \
+                "s_cselect_b32 %[chk], %[nm1], -1\n\t" \
+                "s_add_u32 %[m], %[m], 1\n\t" \
+                "s_cselect_b32 %[chk], -1, %[chk]\n\t" \
+                "s_cmp_le_u32 %[chk], %[limit]\n\t" \
+                "s_cbranch_scc1 1b\n\t" \
+                "s_waitcnt lgkmcnt(0)\n\t" \
+                "s_mov_b64 exec, %[exec_all]\n\t" \
+                "s_mov_b32 m0, %[m0_kept]\n\t" \
+                "s_add_u32 %[m], %[m], 64" \
+                : [pos] "+s"(pos), [m] "+s"(m), [r_pos] "+v"(r_pos), [r_lo] "+v"(r_lo), [r_hi] "+v"(r_hi), \
+                  [lo] "=&s"(lo), [hi] "=&s"(hi), [groups] "=&s"(groups), [t] "=&s"(t), [bytes] "=&s"(bytes), \
+                  [nm1] "=&s"(nm1), [chk] "=&s"(chk), [addr] "=&v"(addr), [exec_all] "=&s"(exec_all), \
+                  [m0_kept] "=&s"(m0_kept) \
+                : [w] "s"(w), [rb] "s"(rb), [limit] "s"(chase_limit), [voff] "v"(voff), \
+                  [voff1] "v"(voff + 1u) \
+                : "v2", "v3", "scc", "memory");
+
+constexpr uint32_t kExplicit = 0x8080u;  // `lo` of a parked record that carries (kind, count, info) itself
+
+// What the chase parked for one run (record of lane i), decoded by lane i: the run's kind, the values it holds
+// before any clamp (mod.rs:41-64), the RLE value (not masked to the bit width) or the a-offset of the bit-packed
+// payload, and the a-offset of the byte behind an RLE run.  `rb`: bytes of an RLE value, `rb_mask`: the first
+// min(4, rb) of them.  Records that carry the explicit marker were decoded by decode_run already.
+struct ParkedRun {
+    uint32_t kind, count, info, after;
+};
+__device__ __forceinline__ ParkedRun decode_parked(uint32_t r_pos, uint32_t r_lo, uint32_t r_hi, uint32_t r_info,
+                                                   uint32_t rb, uint32_t rb_mask) {
+    ParkedRun p;
+    const uint32_t two = (r_lo >> 7) & 1u;
+    const uint32_t groups = ((r_lo >> 1) & 0x3fu) | (two ? (r_lo >> 2) & 0x1fc0u : 0u);
+    const uint32_t rest = two ? __builtin_amdgcn_alignbit(r_hi, r_lo, 16) : __builtin_amdgcn_alignbit(r_hi, r_lo, 8);
+    p.kind = (r_lo & 1u) ^ 1u;
+    p.count = p.kind == kRle ? groups : groups * 8u;
+    p.info = p.kind == kRle ? (rest & rb_mask) : r_pos + 1u + two;
+    p.after = r_pos + 1u + two + rb;
+    if ((~r_lo & kExplicit) == 0u) {
+        p.kind = (r_lo >> 16) & 3u;
+        p.count = r_hi;
+        p.info = r_info;
+        p.after = r_pos + ((r_lo >> 20) & 0xffu);
+    }
+    return p;
+}
+
 }  // namespace pq2

@@ -61,59 +61,6 @@ constexpr int kHalfPieces = (int)(kHalf / 1024u);  // dwordx4 loads of the wave 
 // the last needed one is looked at (and never reported: a header the reference
 // would not reach cannot fail the page).
 // ---------------------------------------------------------------------------
-// The chase loop of parse_kernel (see there).  HI_READ / HI_PARK: the instructions that move the second four
-// bytes behind a header into the record, or nothing.  The statement uses M0 (the lane select of v_writelane) and
-// narrows EXEC to lane 0; it puts both back before it ends, so neither is named as clobbered.
-#define PQ2_CHASE(HI_READ, HI_PARK) \
-asm volatile( \
-                "s_mov_b32 %[m0_kept], m0\n\t" \
-                "s_mov_b64 %[exec_all], exec\n\t" \
-                "s_mov_b64 exec, 1\n\t" \
-                "s_sub_u32 %[m], %[m], 64\n\t" \
-                "v_add_u32 %[addr], %[pos], %[voff]\n\t" \
-                "ds_read_b64 v[2:3], %[addr]\n" \
-                "1:\n\t" \
-                "s_waitcnt lgkmcnt(0)\n\t" \
-                "v_readfirstlane_b32 %[lo], v2\n\t" \
-                "s_bfe_u32 %[groups], %[lo], 0x60001\n\t" \
-                "s_lshr_b32 %[t], %[lo], 2\n\t" \
-                "s_and_b32 %[t], %[t], 0x1fc0\n\t" \
-                "s_bitcmp1_b32 %[lo], 7\n\t" \
-                "s_cselect_b32 %[t], %[t], 0\n\t" \
-                "s_or_b32 %[groups], %[groups], %[t]\n\t" \
-                "s_mul_i32 %[bytes], %[groups], %[w]\n\t" \
-                "s_bitcmp1_b32 %[lo], 0\n\t" \
-                "s_cselect_b32 %[bytes], %[bytes], %[rb]\n\t" \
-                "s_bitcmp1_b32 %[lo], 7\n\t" \
-                "s_addc_u32 %[nm1], %[pos], %[bytes]\n\t" \
-                HI_READ \
-                "v_add_u32 %[addr], %[nm1], %[voff1]\n\t" \
-                "ds_read_b64 v[2:3], %[addr]\n\t" \
-                "s_mov_b32 m0, %[m]\n\t" \
-                "v_writelane_b32 %[r_pos], %[pos], m0\n\t" \
-                "v_writelane_b32 %[r_lo], %[lo], m0\n\t" \
-                HI_PARK \
-                "s_add_u32 %[pos], %[nm1], 1\n\t" \
-                "s_andn2_b32 %[t], 0x8080, %[lo]\n\t" \
-                "s_cselect_b32 %[chk], %[nm1], -1\n\t" \
-                "s_add_u32 %[m], %[m], 1\n\t" \
-                "s_cselect_b32 %[chk], -1, %[chk]\n\t" \
-                "s_cmp_le_u32 %[chk], %[limit]\n\t" \
-                "s_cbranch_scc1 1b\n\t" \
-                "s_waitcnt lgkmcnt(0)\n\t" \
-                "s_mov_b64 exec, %[exec_all]\n\t" \
-                "s_mov_b32 m0, %[m0_kept]\n\t" \
-                "s_add_u32 %[m], %[m], 64" \
-                : [pos] "+s"(pos), [m] "+s"(m), [r_pos] "+v"(r_pos), [r_lo] "+v"(r_lo), [r_hi] "+v"(r_hi), \
-                  [lo] "=&s"(lo), [hi] "=&s"(hi), [groups] "=&s"(groups), [t] "=&s"(t), [bytes] "=&s"(bytes), \
-                  [nm1] "=&s"(nm1), [chk] "=&s"(chk), [addr] "=&v"(addr), [exec_all] "=&s"(exec_all), \
-                  [m0_kept] "=&s"(m0_kept) \
-                : [w] "s"(w), [rb] "s"(rb), [limit] "s"(min(end - 1u, win_lo + kWin - 9u)), [voff] "v"(voff), \
-                  [voff1] "v"(voff + 1u) \
-                : "v2", "v3", "scc", "memory");
-
-constexpr uint32_t kExplicit = 0x8080u;  // `lo` of a parked record that carries (kind, count, info) itself
-
 // The header walk of one page by one wave.  `win` (kWin bytes of LDS, private to the wave) holds stream byte a at
 // win[a - win_lo] for a in [win_lo, win_lo + kWin).  `publish(v)` is called, by all lanes, with the number of
 // values the listed runs cover once the entries that describe them (header positions, Resume) have been stored,
@@ -268,6 +215,7 @@ __device__ __forceinline__ void parse_page(const PageDev &pg, const uint32_t pag
             uint64_t exec_all;
             uint32_t m0_kept;
             const uint32_t voff = lds_base - win_lo;
+            const uint32_t chase_limit = min(end - 1u, win_lo + kWin - 9u);
             // the bytes behind the header's first four are only needed for RLE values of more than two bytes
             if constexpr (kWide) {
                 PQ2_CHASE("v_readfirstlane_b32 %[hi], v3\n\t", "v_writelane_b32 %[r_hi], %[hi], m0\n\t")
@@ -313,23 +261,8 @@ __device__ __forceinline__ void parse_page(const PageDev &pg, const uint32_t pag
         // what the previous pass stored has had this pass's chase to reach memory: announcing it now costs no wait
         if (announce != 0u) publish(announce);
         // ---- place: lane i decodes record i; a prefix sum over the run lengths places the runs -------------
-        uint32_t kind, count, info, after;  // after: a-offset of the byte behind an RLE run
-        {
-            const uint32_t two = (r_lo >> 7) & 1u;
-            const uint32_t groups = ((r_lo >> 1) & 0x3fu) | (two ? (r_lo >> 2) & 0x1fc0u : 0u);
-            const uint32_t rest =
-                two ? __builtin_amdgcn_alignbit(r_hi, r_lo, 16) : __builtin_amdgcn_alignbit(r_hi, r_lo, 8);
-            kind = (r_lo & 1u) ^ 1u;
-            count = kind == kRle ? groups : groups * 8u;         // mod.rs:41-64
-            info = kind == kRle ? (rest & rb_mask) : r_pos + 1u + two;  // RLE value (not masked to w) | payload
-            after = r_pos + 1u + two + rb;
-        }
-        if ((~r_lo & kExplicit) == 0u) {
-            kind = (r_lo >> 16) & 3u;
-            count = r_hi;
-            info = r_info;
-            after = r_pos + ((r_lo >> 20) & 0xffu);
-        }
+        const ParkedRun parked = decode_parked(r_pos, r_lo, r_hi, r_info, rb, rb_mask);
+        const uint32_t kind = parked.kind, count = parked.count, info = parked.info, after = parked.after;
         const uint32_t left = n - produced;  // > 0
         const uint32_t cnt = (lane < m && kind < kEnd) ? min(count, left) : 0u;
         // inclusive prefix sum, saturating at `left` (all terms <= left < 2^31, so no step overflows)

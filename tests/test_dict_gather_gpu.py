@@ -13,13 +13,13 @@ from parquet2_amd.error import InvalidParameter
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["per_tile", "per_page"])
+@pytest.fixture(scope="module", params=["per_tile", "per_page", "ring"])
 def ctx(request):
     import os
 
     from parquet2_amd import Context
 
-    os.environ["PQ2_MODE"] = "tile" if request.param == "per_tile" else "page"
+    os.environ["PQ2_MODE"] = {"per_tile": "tile", "per_page": "page", "ring": "ring"}[request.param]
     try:
         c = Context(0)
     finally:

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Diagnostic: one ring_kernel batch of config-2 pages; prints the status histogram (a PQ2_RING_DEBUG build codes
+the wait that ran out into the status) and the time of a few calls."""
+import sys, time, os
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("PQ2_MODE", "ring")
+from parquet2_amd import PAGE_DESC_DTYPE, Context, synth
+pages_n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+n = 1 << 20
+distinct = [synth.dict_page(synth.seed_for(2, p), n, 12) for p in range(16)]
+stride = (max(len(s) for s, _ in distinct) + 16 + 255) // 256 * 256
+h = np.zeros((16, stride), np.uint8)
+for i, (s, _) in enumerate(distinct): h[i, :len(s)] = s
+d_in = torch.from_numpy(h).cuda()[torch.arange(pages_n, device="cuda") % 16].contiguous()
+d_out = torch.zeros(pages_n * n, dtype=torch.int32, device="cuda")
+descs = np.zeros(pages_n, dtype=PAGE_DESC_DTYPE)
+descs["in_off"] = np.arange(pages_n, dtype=np.uint64) * stride
+descs["in_len"] = [len(distinct[i % 16][0]) for i in range(pages_n)]
+descs["num_bits"] = 12; descs["num_values"] = n; descs["out_off"] = np.arange(pages_n, dtype=np.uint64) * n
+ctx = Context(0)
+calls = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+times = []
+for it in range(calls):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    st = ctx.decode_batch_device(d_in.data_ptr(), d_in.numel(), descs, d_out.data_ptr(), pages_n * n, 0)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    vals, cnt = np.unique(st, return_counts=True)
+    times.append(dt * 1e3)
+    if it < 2 or len(vals) > 1 or vals[0] != 0 or dt > 0.02:
+        print("call %d: %.3f ms, statuses %s" % (it, dt * 1e3, dict(zip(vals.tolist(), cnt.tolist()))), flush=True)
+print("%d pages, %d calls: median %.3f ms, min %.3f, max %.3f" % (pages_n, calls, np.median(times), min(times), max(times)))

@@ -581,12 +581,15 @@ __device__ __forceinline__ void emit_bp_dispatch(uint32_t w, __amdgpu_buffer_rsr
 // (LDS address of stream byte 0 as far as this stretch of the walk is concerned).  HI_READ / HI_PARK: the instructions that move the second four
 // bytes behind a header into the record, or nothing.  The statement uses M0 (the lane select of v_writelane) and
 // narrows EXEC to lane 0; it puts both back before it ends, so neither is named as clobbered.
+// (`m` is kept minus 64 inside: the 64th increment sets the carry, and its low six bits, which select the lane of
+// v_writelane, are those of the record's number)
+#define PQ2_CHASE_RUNS "64"
 #define PQ2_CHASE(HI_READ, HI_PARK) \
 asm volatile( \
                 "s_mov_b32 %[m0_kept], m0\n\t" \
                 "s_mov_b64 %[exec_all], exec\n\t" \
                 "s_mov_b64 exec, 1\n\t" \
-                "s_sub_u32 %[m], %[m], 64\n\t" \
+                "s_sub_u32 %[m], %[m], " PQ2_CHASE_RUNS "\n\t" \
                 "v_add_u32 %[addr], %[pos], %[voff]\n\t" \
                 "ds_read_b64 v[2:3], %[addr]\n" \
                 "1:\n\t" \
@@ -620,7 +623,7 @@ asm volatile( \
                 "s_waitcnt lgkmcnt(0)\n\t" \
                 "s_mov_b64 exec, %[exec_all]\n\t" \
                 "s_mov_b32 m0, %[m0_kept]\n\t" \
-                "s_add_u32 %[m], %[m], 64" \
+                "s_add_u32 %[m], %[m], " PQ2_CHASE_RUNS \
                 : [pos] "+s"(pos), [m] "+s"(m), [r_pos] "+v"(r_pos), [r_lo] "+v"(r_lo), [r_hi] "+v"(r_hi), \
                   [lo] "=&s"(lo), [hi] "=&s"(hi), [groups] "=&s"(groups), [t] "=&s"(t), [bytes] "=&s"(bytes), \
                   [nm1] "=&s"(nm1), [chk] "=&s"(chk), [addr] "=&v"(addr), [exec_all] "=&s"(exec_all), \

@@ -19,21 +19,48 @@
 // once no expanding wave needs them (the lowest needed byte / the lowest held tile), and it says so when it has to
 // wait for room, so that the expanding waves go on with whatever is published instead of waiting for a whole span.
 // Every wait is bounded; a wait that runs out marks the page PQ2_DEVICE_ERROR and ends all four waves.
+#include <stdlib.h>
+
 #include "pq2_device.h"
 
 namespace pq2 {
 
 constexpr uint32_t kSlot = 4096;                // bytes per ring fill
 constexpr uint32_t kMirror = 64;                // bytes behind the ring that repeat its first bytes
-constexpr uint32_t kHq = 512;                   // entries of the header-position queue
-constexpr uint32_t kRq = 64;                    // entries of the block-start queue
-constexpr uint32_t kRingExpanders = 3;
-constexpr uint32_t kSlotsInFlight = 2;          // ring fills the walk keeps in flight
+#ifndef PQ2_RING_EXPANDERS
+#define PQ2_RING_EXPANDERS 3
+#endif
+constexpr uint32_t kRingExpanders = PQ2_RING_EXPANDERS;  // 3 or 4 expanding waves beside the walking one
+constexpr uint32_t kRingThreads = 64u * (kRingExpanders + 1u);
+// the queues share the compute unit's LDS with the ring: four workgroups of 40 KiB each
+constexpr uint32_t kHq = kRingExpanders == 3 ? 512 : 256;  // entries of the header-position queue
+constexpr uint32_t kRq = kRingExpanders == 3 ? 64 : 32;    // entries of the block-start queue
+#ifndef PQ2_RING_SLOTS_IN_FLIGHT
+#define PQ2_RING_SLOTS_IN_FLIGHT 4
+#endif
+constexpr uint32_t kSlotsInFlight = PQ2_RING_SLOTS_IN_FLIGHT;  // ring fills the walk keeps in flight
+constexpr uint32_t kPassRuns = 64;  // runs the walk parks before it places and publishes them (one lane each)
+#ifndef PQ2_RING_PASS_BYTES
+#define PQ2_RING_PASS_BYTES 0xffffffffu
+#endif
+// ... or once the parked runs span this many stream bytes: what is parked is not published, so nobody can take
+// it out of the ring yet
+constexpr uint32_t kPassBytes = PQ2_RING_PASS_BYTES;
+#ifndef PQ2_RING_WALK_PRIO
+#define PQ2_RING_WALK_PRIO 2
+#endif
 constexpr uint32_t kNotYet = 0xfffffffeu;       // header position of a run the walk has not published yet
 constexpr uint32_t kTileFresh = 0xffffffffu;    // "lowest byte needed" of a wave that has not looked at its tile yet
 constexpr uint32_t kNoNeed = 0xffffffc0u;       // ... of a wave that needs no stream byte any more
 constexpr uint32_t kRingMaxPolls = 1u << 22;    // of >= 0.1 us each: far beyond any wait of a healthy page
 
+#ifndef PQ2_RING_TILE_BLOCKS
+#define PQ2_RING_TILE_BLOCKS 4
+#endif
+// What an expanding wave takes at a time: a tile of this many 1024-value blocks (smaller than the tiles of the
+// other kernels if that pays: the bytes of the tiles in progress are what keeps the ring occupied).
+constexpr uint32_t kRingTileBlocks = PQ2_RING_TILE_BLOCKS;  // 2 or 4
+constexpr uint32_t kRingTileValues = kRingTileBlocks * kBlockValues;
 constexpr uint32_t kRingTableRuns = 64;                      // run-table entries per expanding wave
 constexpr uint32_t kRingSpanBlocks = 2;                      // blocks per span
 constexpr uint32_t kRingSpanValues = kRingSpanBlocks * kBlockValues;
@@ -55,6 +82,26 @@ struct RingCtl {
     uint32_t pick[8];      // pick_walker's scratch
 };
 constexpr uint32_t kRingAllParsed = 0xffffffffu;
+
+#ifdef PQ2_RING_TIMING  // diagnostic build: shader clocks spent per role and wait, summed over all waves
+// 0 walk total, 1 walk waiting for room, 2 walk waiting for fills, 3 walk chase, 4 walk after its last publish,
+// 8 expand total, 9 waiting for a block start, 10 waiting for runs, 11 waiting for bytes
+__device__ unsigned long long g_ring_clocks[32];  // 16..: event counts of the walk (see PQ2_COUNT uses)
+#define PQ2_CLOCK() __builtin_amdgcn_s_memtime()
+#define PQ2_CLOCK_ADD(SLOT, T0) clocks[(SLOT) & 7] += __builtin_amdgcn_s_memtime() - (T0)
+#define PQ2_COUNT(SLOT, V) counts[SLOT] += (V)
+#define PQ2_CLOCK_FLUSH(BASE)                                                                            \
+    do {                                                                                                 \
+        if (lane == 0)                                                                                   \
+            for (int i_ = 0; i_ < 8; ++i_)                                                               \
+                if (clocks[i_]) atomicAdd(&g_ring_clocks[(BASE) + i_], (unsigned long long)clocks[i_]);  \
+    } while (0)
+#else
+#define PQ2_CLOCK() 0ull
+#define PQ2_CLOCK_ADD(SLOT, T0) do { (void)(T0); } while (0)
+#define PQ2_CLOCK_FLUSH(BASE) do { } while (0)
+#define PQ2_COUNT(SLOT, V) do { } while (0)
+#endif
 
 // LDS bytes of one workgroup for a ring of `ring_bytes`
 __host__ __device__ constexpr uint32_t ring_lds_bytes(uint32_t ring_bytes) {
@@ -89,14 +136,18 @@ template <bool kWide>
 __device__ __forceinline__ void ring_walk(const PageDev &pg, const uint32_t page, const RingShared sh,
                                           int32_t *__restrict__ status, const uint32_t lane) {
     RingCtl *const ctl = sh.ctl;
+#ifdef PQ2_RING_TIMING
+    uint64_t clocks[8] = {};
+    uint64_t counts[12] = {};
+#endif
+    const uint64_t clock_begin = PQ2_CLOCK();
     const uint32_t n = pg.num_values;  // > 0
     const uint32_t w = pg.num_bits;
     const uint32_t n_blocks = (n + kBlockValues - 1u) / kBlockValues;
-    const uint32_t n_tiles = (n + kTileValues - 1u) / kTileValues;
+    const uint32_t n_tiles = (n + kRingTileValues - 1u) / kRingTileValues;
     const uint32_t R = sh.ring_bytes, rmask = R - 1u;
     const uint32_t delta = (uint32_t)(pg.in_addr & 15u);
     const uint32_t end = delta + pg.in_len;  // a-offset one past the last stream byte
-    const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(pg.in_addr - delta, (end + 3u) & ~3u);
     const uint32_t rb = ceil8(w);
     const uint32_t rb_mask = rb < 4 ? (1u << (rb * 8u)) - 1u : ~0u;
     const uint32_t ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)sh.ring;
@@ -129,8 +180,8 @@ __device__ __forceinline__ void ring_walk(const PageDev &pg, const uint32_t page
             low_tile = min(low_tile, tile);
             if (byte == kTileFresh) {
                 // it has not read its tile's first Resume entry yet: the entry says what it will ask for
-                if (tile * kBlocksPerTile >= blocks_done) continue;  // not even written: nothing below the walk
-                const Resume r = sh.rq[(tile * kBlocksPerTile) & (kRq - 1u)];
+                if (tile * kRingTileBlocks >= blocks_done) continue;  // not even written: nothing below the walk
+                const Resume r = sh.rq[(tile * kRingTileBlocks) & (kRq - 1u)];
                 const uint32_t rem_kind = __builtin_amdgcn_readfirstlane(r.rem_kind);
                 const uint32_t payload = __builtin_amdgcn_readfirstlane(r.payload);
                 const uint32_t skip = __builtin_amdgcn_readfirstlane(r.skip);
@@ -139,6 +190,12 @@ __device__ __forceinline__ void ring_walk(const PageDev &pg, const uint32_t page
             low_byte = min(low_byte, byte);
         }
     };
+    // What limits() said last, lowered wherever the truth may since have dropped below it: the needs of the expanding
+    // waves only rise, except that a wave whose tile had no entry yet (no need) gets one when the walk publishes
+    // the tile -- never below the first byte published then (`keep` at that time).  The checks on the walk's way
+    // look at these and ask again only when they fail.
+    uint32_t known_byte = 0, known_tile = 0;
+    auto refresh = [&]() { limits(known_byte, known_tile); };
     auto abort_all = [&]() {
 #ifdef PQ2_RING_DEBUG
         if (lane == 0 && lds_load(&ctl->abort) == 0u) status[page] = 100 + (int32_t)dbg_site;
@@ -149,38 +206,89 @@ __device__ __forceinline__ void ring_walk(const PageDev &pg, const uint32_t page
         aborted = true;
     };
     // ---- ring fills ------------------------------------------------------------------------------------------
+    // The four loads of a fill are written in assembly so that the compiler does not know of them: it would wait for
+    // every load in flight in front of each LDS store of the walk (it cannot tell that they go elsewhere), and the
+    // fills are meant to stay in flight while the walk goes on.  land() waits for them by count.
+    // M0: LDS address of the destination; lane l's 16 bytes land at M0 + 16 l.
+    const u32x4 rsrc_words = {(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(pg.in_addr - delta)),
+                              (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)((pg.in_addr - delta) >> 32) & 0xffffu),
+                              (uint32_t)__builtin_amdgcn_readfirstlane((end + 3u) & ~3u), 0x00020000u};
     auto issue_slot = [&]() {
-        const uint32_t at = issued_hi & rmask;
-        __attribute__((address_space(3))) uint8_t *dst = (__attribute__((address_space(3))) uint8_t *)sh.ring + at;
-#pragma unroll
-        for (uint32_t i = 0; i < kSlot / 1024u; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst + i * 1024u, 16, issued_hi + i * 1024u + lane * 16u, 0, 0, 0);
-        if (at == 0u && lane < kMirror / 4u)  // the ring's first bytes once more behind its end
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                rsrc, (__attribute__((address_space(3))) uint8_t *)sh.ring + R, 4, issued_hi + lane * 4u, 0, 0, 0);
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(ring_lds + (issued_hi & rmask));
+        const uint32_t off0 = issued_hi + lane * 16u, off1 = off0 + 1024u, off2 = off0 + 2048u, off3 = off0 + 3072u;
+        uint32_t m0_was;
+        asm volatile(
+            "s_mov_b32 %[m0_was], m0\n\t"
+            "s_mov_b32 m0, %[dst]\n\t"
+            "s_nop 0\n\t"
+            "buffer_load_dwordx4 %[off0], %[rsrc], 0 offen lds\n\t"
+            "s_add_u32 m0, m0, 0x400\n\t"
+            "s_nop 0\n\t"
+            "buffer_load_dwordx4 %[off1], %[rsrc], 0 offen lds\n\t"
+            "s_add_u32 m0, m0, 0x400\n\t"
+            "s_nop 0\n\t"
+            "buffer_load_dwordx4 %[off2], %[rsrc], 0 offen lds\n\t"
+            "s_add_u32 m0, m0, 0x400\n\t"
+            "s_nop 0\n\t"
+            "buffer_load_dwordx4 %[off3], %[rsrc], 0 offen lds\n\t"
+            "s_mov_b32 m0, %[m0_was]"
+            : [m0_was] "=&s"(m0_was)
+            : [dst] "s"(dst), [rsrc] "s"(rsrc_words), [off0] "v"(off0), [off1] "v"(off1), [off2] "v"(off2),
+              [off3] "v"(off3)
+            : "memory", "scc");
         issued_hi += kSlot;
     };
     // may the slot at issued_hi be filled, if nothing below `low` is needed?  (it replaces bytes [issued_hi - R, ...))
     auto room_for_slot = [&](uint32_t low) { return (uint64_t)issued_hi + kSlot <= (uint64_t)(low & ~63u) + R; };
-    auto top_up = [&](uint32_t keep_from) {
-        uint32_t low_byte, low_tile;
-        limits(low_byte, low_tile);
-        low_byte = min(low_byte, keep_from);
-        while (issued_hi < final_hi && issued_hi - landed_hi < kSlotsInFlight * kSlot && room_for_slot(low_byte))
+    // Requests ring fills as far as there is room and the in-flight limit allows.  `ask`: when the room known so far
+    // does not do, look again at what the expanding waves need (a handful of LDS round trips: only where a fill is
+    // needed now, not for the ones requested ahead).
+    auto top_up = [&](uint32_t keep_from, bool ask) {
+        while (issued_hi < final_hi && issued_hi - landed_hi < kSlotsInFlight * kSlot) {
+            if (!room_for_slot(min(known_byte, keep_from))) {
+                if (!ask) break;
+                refresh();
+                ask = false;
+                PQ2_COUNT(2, 1);  // looks at the limits because a fill was needed
+                if (!room_for_slot(min(known_byte, keep_from))) {
+                    PQ2_COUNT(3, 1);  // ... in vain
+                    break;
+                }
+            }
             issue_slot();
+        }
     };
+    // Waits for the oldest fill in flight (the memory operations of a wave complete in order, so that is "all but
+    // the instructions of the fills requested after it") and says that its bytes are there.
     auto land = [&]() {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        landed_hi = issued_hi;
+        PQ2_COUNT(1, 1);  // fills waited for
+        const uint64_t clock_land = PQ2_CLOCK();
+        static_assert(kSlot / 1024u == 4u && kSlotsInFlight <= 4u, "the waits below spell out four loads per fill");
+        const uint32_t behind = (issued_hi - landed_hi) / kSlot - 1u;  // fills requested after the oldest one
+        if (behind == 0u)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (behind == 1u)
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (behind == 2u)
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        PQ2_CLOCK_ADD(2, clock_land);
+        if ((landed_hi & rmask) == 0u) {  // the ring's first bytes once more behind its end
+            if (lane < kMirror / 4u) ((uint32_t *)(sh.ring + R))[lane] = ((const uint32_t *)sh.ring)[lane];
+            lds_release();
+        }
+        landed_hi += kSlot;
         lds_store(&ctl->landed, landed_hi);
     };
     // Waits until `ready(low_byte, low_tile)`; tells the expanding waves that the walk stands still meanwhile.
     auto wait_room = [&](auto ready) {
-        uint32_t low_byte, low_tile;
+        if (ready(known_byte, known_tile)) return;
         bool told = false;
+        const uint64_t clock_wait = PQ2_CLOCK();
         for (uint32_t polls = 0;; ++polls) {
-            limits(low_byte, low_tile);
-            if (ready(low_byte, low_tile)) break;
+            refresh();
+            if (ready(known_byte, known_tile)) break;
             if (!told) {
                 lds_store(&ctl->blocked, 1u);
                 told = true;
@@ -191,11 +299,12 @@ __device__ __forceinline__ void ring_walk(const PageDev &pg, const uint32_t page
             }
             // The ring is kept as full as the room allows meanwhile: an expanding wave may be waiting for the
             // bytes of a run that is published already, and it is that wave's progress that makes the room.
-            top_up(keep);
+            top_up(keep, false);  // (refreshed above)
             if (issued_hi != landed_hi) land();
             __builtin_amdgcn_s_sleep(2);
         }
         if (told) lds_store(&ctl->blocked, 0u);
+        PQ2_CLOCK_ADD(1, clock_wait);
     };
 
     // Makes stream bytes [at, at + bytes) resident as far as that takes no waiting for the expanding waves
@@ -203,10 +312,13 @@ __device__ __forceinline__ void ring_walk(const PageDev &pg, const uint32_t page
     auto try_ensure = [&](uint32_t at, uint32_t bytes) -> bool {
         const uint32_t want = min(at + bytes, final_hi);
         while (landed_hi < want) {
-            top_up(keep);
-            if (issued_hi == landed_hi) return false;
+            if (issued_hi == landed_hi) {
+                PQ2_COUNT(4, 1);  // bytes needed with no fill in flight
+                top_up(keep, true);
+                if (issued_hi == landed_hi) return false;
+            }
             land();
-            top_up(keep);  // the next fills are on their way while the walk works through these
+            top_up(keep, false);  // the next fills are on their way while the walk works through these
         }
         return true;
     };
@@ -225,6 +337,7 @@ __device__ __forceinline__ void ring_walk(const PageDev &pg, const uint32_t page
     // runs first, floor second: a reader that takes the floor first and the run count second knows that every
     // run from that count on starts at or behind that floor
     auto publish = [&](uint32_t covered, uint32_t floor_pos) {
+        known_byte = min(known_byte, keep);  // what becomes visible now lies behind `keep`, and so will its takers' needs
         lds_release();
         lds_store(&ctl->runs, n_runs);
         lds_store(&ctl->floor, floor_pos);
@@ -246,7 +359,7 @@ __device__ __forceinline__ void ring_walk(const PageDev &pg, const uint32_t page
             uint32_t allowed = b;
             PQ2_SITE(2);
             wait_room([&](uint32_t, uint32_t low_tile) {
-                allowed = low_tile == 0xffffffffu ? to : min(to, low_tile * kBlocksPerTile + kRq);
+                allowed = low_tile == 0xffffffffu ? to : min(to, low_tile * kRingTileBlocks + kRq);
                 return allowed > b;
             });
             if (aborted) break;
@@ -291,7 +404,16 @@ __device__ __forceinline__ void ring_walk(const PageDev &pg, const uint32_t page
     uint32_t pos = delta;  // a-offset of the next header
     for (;;) {
         keep = pos;  // everything before is placed and published: the waves that expand it say what they need
+        const uint64_t clock_top = PQ2_CLOCK();
+        refresh();  // once per pass
+        PQ2_COUNT(5, 1);                                   // passes
+        PQ2_COUNT(6, keep - min(known_byte, keep));        // bytes between the lowest need and the first unplaced run
+        PQ2_COUNT(7, landed_hi - min(landed_hi, keep));    // bytes landed ahead of the walk
+        PQ2_COUNT(8, issued_hi - landed_hi);               // bytes in flight
+        top_up(keep, false);
+        PQ2_COUNT(9, issued_hi - landed_hi);               // ... after topping up
         ensure(pos, 32u);
+        PQ2_CLOCK_ADD(6, clock_top);
         if (aborted) return;
         // ---- chase: park up to 64 runs, record i in lane i (see PQ2_CHASE) ---------------------------------
         uint32_t r_pos = 0, r_lo = 0, r_hi = 0, r_info = 0;
@@ -305,11 +427,14 @@ __device__ __forceinline__ void ring_walk(const PageDev &pg, const uint32_t page
             // stops at the end of the stream, of the bytes that have landed, and of this turn of the ring (the
             // mirror holds the 8 bytes of a header that begins in the ring's last bytes)
             const uint32_t chase_limit = __builtin_amdgcn_readfirstlane(min(min(end - 1u, landed_hi - 9u), pos | rmask));
+            PQ2_COUNT(0, 1);  // entries into the chase loop
+            const uint64_t clock_chase = PQ2_CLOCK();
             if constexpr (kWide) {
                 PQ2_CHASE("v_readfirstlane_b32 %[hi], v3\n\t", "v_writelane_b32 %[r_hi], %[hi], m0\n\t")
             } else {
                 PQ2_CHASE("", "")
             }
+            PQ2_CLOCK_ADD(3, clock_chase);
             if ((~lo & kExplicit) == 0u || nm1 > end - 1u) {
                 // three or more header bytes, a run cut by the end of the stream, or the end itself: the record
                 // parked last does not count
@@ -342,9 +467,13 @@ __device__ __forceinline__ void ring_walk(const PageDev &pg, const uint32_t page
                 }
                 pos = run.next;
             }
-            if (m == 64u) break;
-            if (!try_ensure(pos, 9u)) break;
+            if (m == kPassRuns || pos - keep >= kPassBytes) break;
+            const uint64_t clock_more = PQ2_CLOCK();
+            const bool more = try_ensure(pos, 9u);
+            PQ2_CLOCK_ADD(7, clock_more);
+            if (!more) break;
         }
+        const uint64_t clock_place = PQ2_CLOCK();
 
         // ---- place: lane i decodes record i; a prefix sum over the run lengths places the runs -------------
         const ParkedRun parked = decode_parked(r_pos, r_lo, r_hi, r_info, rb, rb_mask);
@@ -376,7 +505,7 @@ __device__ __forceinline__ void ring_walk(const PageDev &pg, const uint32_t page
                 uint32_t allowed = blocks_done;
                 PQ2_SITE(4);
                 wait_room([&](uint32_t, uint32_t low_tile) {
-                    allowed = low_tile == 0xffffffffu ? pass_last + 1u : min(pass_last + 1u, low_tile * kBlocksPerTile + kRq);
+                    allowed = low_tile == 0xffffffffu ? pass_last + 1u : min(pass_last + 1u, low_tile * kRingTileBlocks + kRq);
                     return allowed > blocks_done;
                 });
                 if (aborted) return;
@@ -423,6 +552,7 @@ __device__ __forceinline__ void ring_walk(const PageDev &pg, const uint32_t page
         produced += total;
         publish(min(produced, n), pos);
         keep = pos;
+        PQ2_CLOCK_ADD(5, clock_place);
         if (produced >= n) {
             finish(0, pos);
             break;
@@ -433,6 +563,7 @@ __device__ __forceinline__ void ring_walk(const PageDev &pg, const uint32_t page
         }
     }
     // ---- the rest of the stream the expanding waves ask for -----------------------------------------------------
+    const uint64_t clock_tail = PQ2_CLOCK();
     while (!aborted && issued_hi < final_hi) {
         uint32_t low_tile = 0;
         PQ2_SITE(5);
@@ -441,10 +572,17 @@ __device__ __forceinline__ void ring_walk(const PageDev &pg, const uint32_t page
             return lt == 0xffffffffu || issued_hi >= final_hi || room_for_slot(lb);
         });
         if (aborted || low_tile == 0xffffffffu) break;  // every tile is done
-        top_up(0xffffffffu);
-        land();
+        top_up(0xffffffffu, true);
+        while (issued_hi != landed_hi) land();
     }
-    if (issued_hi != landed_hi) land();  // fills that were still on their way when the walk ended
+    while (issued_hi != landed_hi) land();  // fills that were still on their way when the walk ended
+    PQ2_CLOCK_ADD(4, clock_tail);
+    PQ2_CLOCK_ADD(0, clock_begin);
+    PQ2_CLOCK_FLUSH(0);
+#ifdef PQ2_RING_TIMING
+    if (lane == 0)
+        for (int i = 0; i < 12; ++i) atomicAdd(&g_ring_clocks[16 + i], (unsigned long long)counts[i]);
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -459,6 +597,9 @@ struct RingExpander {
     int32_t *status;
     uint32_t page;
     bool aborted;
+#ifdef PQ2_RING_TIMING
+    uint64_t clocks[8];
+#endif
 
     __device__ __forceinline__ void say(uint32_t lane) {
         if (lane == 0)
@@ -483,6 +624,7 @@ struct RingExpander {
     }
     // Waits until the ring holds the stream up to `to` (or all it will ever hold); `to` lies within `cap` of `need`.
     __device__ __forceinline__ void await_bytes(uint32_t to, uint32_t lane) {
+        const uint64_t clock_wait = PQ2_CLOCK();
         for (uint32_t polls = 0;; ++polls) {
             const uint32_t landed = lds_load(&sh.ctl->landed);
             const uint32_t final_hi = lds_load(&sh.ctl->final_hi);
@@ -493,10 +635,12 @@ struct RingExpander {
             }
             __builtin_amdgcn_s_sleep(2);
         }
+        PQ2_CLOCK_ADD(11, clock_wait);
         lds_acquire();
     }
     // Waits until the walk has covered value `first` (the Resume entry of the block that starts there is written).
     __device__ __forceinline__ void await_start(uint32_t first, uint32_t lane) {
+        const uint64_t clock_wait = PQ2_CLOCK();
         for (uint32_t polls = 0;; ++polls) {
             if (lds_load(&sh.ctl->covered) > first) break;
             if (polls == kRingMaxPolls || lds_load(&sh.ctl->abort) != 0u) {
@@ -505,6 +649,7 @@ struct RingExpander {
             }
             __builtin_amdgcn_s_sleep(2);
         }
+        PQ2_CLOCK_ADD(9, clock_wait);
         lds_acquire();
     }
     // Number of published runs once a pass from run `ridx` on has what it can get: the walk has covered the span
@@ -513,6 +658,7 @@ struct RingExpander {
     // then the wave needs no byte below the walk's floor any more and says so.
     __device__ __forceinline__ uint32_t await_runs(uint32_t ridx, uint32_t span_end, bool must, uint32_t lane) {
         uint32_t runs = 0;
+        const uint64_t clock_wait = PQ2_CLOCK();
         for (uint32_t polls = 0;; ++polls) {
             const uint32_t floor = lds_load(&sh.ctl->floor);  // before the run count: see ring_walk's publish
             lds_acquire();
@@ -532,6 +678,7 @@ struct RingExpander {
             }
             __builtin_amdgcn_s_sleep(2);
         }
+        PQ2_CLOCK_ADD(10, clock_wait);
         lds_acquire();
         return runs;
     }
@@ -563,6 +710,10 @@ __device__ __forceinline__ void ring_expand_span(RingExpander &io, uint2 *tbl, u
 
     do {
         // ---- phase 1: the runs that cover [lo, hi) into the table ------------------------------------
+#ifdef PQ2_RING_TIMING
+        uint64_t *const clocks = io.clocks;
+#endif
+        const uint64_t clock_p1 = PQ2_CLOCK();
         uint32_t take0 = min(rem, block_n - lo);
         uint32_t y0 = payload;
         bool alone = take0 == block_n - lo;
@@ -647,6 +798,8 @@ __device__ __forceinline__ void ring_expand_span(RingExpander &io, uint2 *tbl, u
                 hi = (start_g >= block_n || ends) ? block_n : start_g;
             }
             tbl[(lane + 1u) & 63u] = lane == 63u ? make_uint2((lo << 1) | kind, y0) : make_uint2(key, y);
+            PQ2_CLOCK_ADD(4, clock_p1);
+            const uint64_t clock_ix = PQ2_CLOCK();
             // ---- index: the run that holds the first position of every chunk ---------------------------
             // The runs' first positions ascend with the lane, so do the chunks they mark: of the lanes that mark
             // one chunk the last one's number is the one to keep, and it is the only one that writes.
@@ -686,6 +839,8 @@ __device__ __forceinline__ void ring_expand_span(RingExpander &io, uint2 *tbl, u
                 __builtin_amdgcn_wave_barrier();
             }
 
+            PQ2_CLOCK_ADD(5, clock_ix);
+            const uint64_t clock_p2 = PQ2_CLOCK();
             // ---- phase 2: one chunk per lane and step ---------------------------------------------------
             const uint32_t q_end = (hi + mis + 3u) >> 2;
             const uint32_t q_first = ((lo + mis) >> 2) + lane;
@@ -734,6 +889,8 @@ __device__ __forceinline__ void ring_expand_span(RingExpander &io, uint2 *tbl, u
                         ragged = ragged | (single & !full);
                     }
             }
+            PQ2_CLOCK_ADD(6, clock_p2);
+            const uint64_t clock_st = PQ2_CLOCK();
             if (__builtin_expect(__ballot(ragged) != 0, 0)) {
 #pragma unroll
                 for (uint32_t side = 0; side < 2u; ++side) {
@@ -781,6 +938,7 @@ __device__ __forceinline__ void ring_expand_span(RingExpander &io, uint2 *tbl, u
                 for (int k = 0; k < 4; ++k)
                     if (p + k >= (int32_t)lo && p + k < (int32_t)hi) out[p + k] = (cur[k].x & 1u) ? cur[k].y : f[k];
             }
+            PQ2_CLOCK_ADD(7, clock_st);
             // ---- next pass: run ridx + 1 + g becomes the first run -----------------------------------------
             if (hi < block_n && !alone) {
                 ridx += 1u + g;
@@ -830,17 +988,20 @@ __device__ __forceinline__ uint32_t ring_pick_walker(uint32_t *cu_tickets, uint3
     const uint32_t xcc_id = __builtin_amdgcn_s_getreg((3 << 11) | 20);  // HW_REG_XCC_ID
     if (lane == 0) scratch[wave] = (hw_id >> 4) & 3u;                   // SIMD_ID
     if (threadIdx.x == 0)
-        scratch[4] = atomicAdd(&cu_tickets[(((hw_id >> 8) & 0xffu) | (xcc_id << 8)) & (kRingCuTickets - 1u)], 1u);
+        scratch[7] = atomicAdd(&cu_tickets[(((hw_id >> 8) & 0xffu) | (xcc_id << 8)) & (kRingCuTickets - 1u)], 1u);
     __syncthreads();
-    const uint32_t target = scratch[4] & 3u;
+    const uint32_t target = scratch[7] & 3u;
     uint32_t walker = 0;
-    for (uint32_t k = 4; k-- > 0;)
+    for (uint32_t k = kRingExpanders + 1u; k-- > 0;)
         if (scratch[k] == target) walker = k;
     return __builtin_amdgcn_readfirstlane(walker);
 }
 
+#ifndef PQ2_RING_MIN_WAVES
+#define PQ2_RING_MIN_WAVES 4
+#endif
 template <bool kWide>
-__global__ __launch_bounds__(256, 4) void ring_kernel(const PageDev *__restrict__ pages, uint32_t n_pages,
+__global__ __launch_bounds__(kRingThreads, PQ2_RING_MIN_WAVES) void ring_kernel(const PageDev *__restrict__ pages, uint32_t n_pages,
                                                        int32_t *__restrict__ status, uint32_t *__restrict__ cu_tickets,
                                                        uint32_t ring_bytes, const uint32_t *__restrict__ tile_mask) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -862,7 +1023,7 @@ __global__ __launch_bounds__(256, 4) void ring_kernel(const PageDev *__restrict_
     sh.rq = (Resume *)(lds + ring_bytes + kMirror + kHq * 4u);
     sh.ctl = (RingCtl *)(lds + ring_bytes + kMirror + kHq * 4u + kRq * 16u);
     uint8_t *const tables = (uint8_t *)sh.ctl + sizeof(RingCtl);
-    const uint32_t n_tiles = (n + kTileValues - 1u) / kTileValues;
+    const uint32_t n_tiles = (n + kRingTileValues - 1u) / kRingTileValues;
     if (threadIdx.x < sizeof(RingCtl) / 4u) ((uint32_t *)sh.ctl)[threadIdx.x] = 0u;
     __syncthreads();
     if (threadIdx.x < kRingExpanders)  // the first tiles are handed out here: wave e holds tile e
@@ -871,6 +1032,7 @@ __global__ __launch_bounds__(256, 4) void ring_kernel(const PageDev *__restrict_
     const uint32_t walker = ring_pick_walker(cu_tickets, sh.ctl->pick, wave, lane);  // with a workgroup barrier inside
 
     if (wave == walker) {
+        if (PQ2_RING_WALK_PRIO != 0) __builtin_amdgcn_s_setprio(PQ2_RING_WALK_PRIO);
         ring_walk<kWide>(pg, page, sh, status, lane);
         return;
     }
@@ -886,25 +1048,30 @@ __global__ __launch_bounds__(256, 4) void ring_kernel(const PageDev *__restrict_
     io.status = status;
     io.page = page;
     io.aborted = false;
+#ifdef PQ2_RING_TIMING
+    for (int i = 0; i < 8; ++i) io.clocks[i] = 0;
+    uint64_t *const clocks = io.clocks;
+#endif
     const uint32_t w = pg.num_bits;
     const uint32_t delta = (uint32_t)(pg.in_addr & 15u);
     const uint32_t end = delta + pg.in_len;
 
+    const uint64_t clock_begin = PQ2_CLOCK();
     for (uint32_t t = e; t < n_tiles;) {
         io.tile = t;
         io.need = kTileFresh;
         io.say(lane);
-        if (ring_tile_wanted(pg, tile_mask, t)) {
-            const uint32_t tile_first = t * kTileValues;
+        if (ring_tile_wanted(pg, tile_mask, t * kRingTileBlocks / kBlocksPerTile)) {
+            const uint32_t tile_first = t * kRingTileValues;
             out_u32 *const out = (out_u32 *)pg.out_addr + tile_first;
-            constexpr uint32_t kSpans = kBlocksPerTile / kRingSpanBlocks;
+            constexpr uint32_t kSpans = kRingTileBlocks / kRingSpanBlocks;
             for (uint32_t i = 0; i < kSpans; ++i) {
                 const uint32_t span_first = tile_first + i * kRingSpanValues;
                 if (span_first >= n) break;
                 const uint32_t span_n = min(kRingSpanValues, n - span_first);
                 io.await_start(span_first, lane);
                 if (io.aborted) return;
-                const u32x4 r4 = *(const u32x4 *)&sh.rq[(t * kBlocksPerTile + i * kRingSpanBlocks) & (kRq - 1u)];
+                const u32x4 r4 = *(const u32x4 *)&sh.rq[(t * kRingTileBlocks + i * kRingSpanBlocks) & (kRq - 1u)];
                 Resume rs;
                 rs.run_index = __builtin_amdgcn_readfirstlane(r4.x);
                 rs.rem_kind = __builtin_amdgcn_readfirstlane(r4.y);
@@ -950,9 +1117,20 @@ __global__ __launch_bounds__(256, 4) void ring_kernel(const PageDev *__restrict_
     io.tile = 0xffffffffu;  // through: the walk no longer counts on this wave
     io.need = kNoNeed;
     io.say(lane);
+    PQ2_CLOCK_ADD(8, clock_begin);
+    PQ2_CLOCK_FLUSH(8);
 }
 
 }  // namespace pq2
+
+#ifdef PQ2_RING_TIMING
+// copies the clock sums to `out` (16 values) and clears them
+extern "C" int pq2_ring_clocks(unsigned long long *out) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pq2::g_ring_clocks), sizeof(pq2::g_ring_clocks)) != hipSuccess) return 1;
+    unsigned long long zero[32] = {};
+    return hipMemcpyToSymbol(HIP_SYMBOL(pq2::g_ring_clocks), zero, sizeof(zero)) != hipSuccess;
+}
+#endif
 
 extern "C" uint32_t pq2_ring_ticket_bytes() { return pq2::kRingCuTickets * 4u; }
 
@@ -961,17 +1139,23 @@ extern "C" uint32_t pq2_ring_ticket_bytes() { return pq2::kRingCuTickets * 4u; }
 extern "C" hipError_t pq2_launch_ring(const void *pages, uint32_t n_pages, int32_t *status, uint32_t *cu_tickets,
                                       uint32_t max_bits, const uint32_t *tile_mask, hipStream_t stream) {
     if (n_pages == 0) return hipSuccess;
-    const uint32_t ring_bytes = max_bits > 16u ? 65536u : 32768u;
+    uint32_t ring_bytes = max_bits > 16u ? 65536u : 32768u;
+    if (const char *v = getenv("PQ2_RING_BYTES")) {  // tuning knob: 16384, 32768 or 65536
+        const uint32_t b = (uint32_t)atoi(v);
+        if (b == 16384u || b == 32768u || b == 65536u) ring_bytes = b;
+    }
     const uint32_t lds_bytes = pq2::ring_lds_bytes(ring_bytes);
     if (max_bits > 16u) {
         // more than 64 KiB of dynamic LDS has to be asked for (per device; the call is cheap)
-        hipError_t e = hipFuncSetAttribute((const void *)pq2::ring_kernel<true>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(pq2::ring_kernel<true>, dim3(n_pages), dim3(256), lds_bytes, stream,
+        if (lds_bytes > 65536u) {
+            hipError_t e = hipFuncSetAttribute((const void *)pq2::ring_kernel<true>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(pq2::ring_kernel<true>, dim3(n_pages), dim3(pq2::kRingThreads), lds_bytes, stream,
                            (const pq2::PageDev *)pages, n_pages, status, cu_tickets, ring_bytes, tile_mask);
     } else {
-        hipLaunchKernelGGL(pq2::ring_kernel<false>, dim3(n_pages), dim3(256), lds_bytes, stream,
+        hipLaunchKernelGGL(pq2::ring_kernel<false>, dim3(n_pages), dim3(pq2::kRingThreads), lds_bytes, stream,
                            (const pq2::PageDev *)pages, n_pages, status, cu_tickets, ring_bytes, tile_mask);
     }
     return hipGetLastError();

@@ -30,3 +30,28 @@ for it in range(calls):
     if it < 2 or len(vals) > 1 or vals[0] != 0 or dt > 0.02:
         print("call %d: %.3f ms, statuses %s" % (it, dt * 1e3, dict(zip(vals.tolist(), cnt.tolist()))), flush=True)
 print("%d pages, %d calls: median %.3f ms, min %.3f, max %.3f" % (pages_n, calls, np.median(times), min(times), max(times)))
+
+import ctypes
+from parquet2_amd import _lib
+h = _lib.lib()
+if hasattr(h, "pq2_ring_clocks"):  # a PQ2_RING_TIMING build
+    buf = (ctypes.c_ulonglong * 32)()
+    h.pq2_ring_clocks(buf)  # clear
+    ctx.decode_batch_device(d_in.data_ptr(), d_in.numel(), descs, d_out.data_ptr(), pages_n * n, 0)
+    torch.cuda.synchronize()
+    h.pq2_ring_clocks(buf)
+    c = [float(x) for x in buf]
+    print("walk:   total %.0f clocks/page; room %.1f%%, fills %.1f%%, chase %.1f%%, tail %.1f%%, place %.1f%%, "
+          "ensure at the top %.1f%%, more bytes inside a pass %.1f%% (fills are inside the last two)" %
+          (c[0] / pages_n, 100 * c[1] / c[0], 100 * c[2] / c[0], 100 * c[3] / c[0], 100 * c[4] / c[0],
+           100 * c[5] / c[0], 100 * c[6] / c[0], 100 * c[7] / c[0]))
+    print("expand: total %.0f clocks/wave; waits: block start %.1f%%, runs %.1f%%, bytes %.1f%%; phase 1 %.1f%% (its waits "
+          "included), index %.1f%%, phase 2 %.1f%%, run starts %.1f%%" %
+          (c[8] / pages_n / 3, 100 * c[9] / c[8], 100 * c[10] / c[8], 100 * c[11] / c[8], 100 * c[12] / c[8],
+           100 * c[13] / c[8], 100 * c[14] / c[8], 100 * c[15] / c[8]))
+    k = c[16:28]
+    print("walk counts per page: chase entries %.0f, fills waited for %.0f, looks at the limits %.0f (in vain %.0f), "
+          "bytes needed with nothing in flight %.0f, passes %.0f" % tuple(x / pages_n for x in k[:6]))
+    if k[5]:
+        print("at the top of a pass, on average: lowest need %.0f bytes behind the walk, %.0f bytes landed ahead, "
+              "%.0f in flight, %.0f after topping up" % (k[6] / k[5], k[7] / k[5], k[8] / k[5], k[9] / k[5]))

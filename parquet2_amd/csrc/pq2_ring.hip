@@ -798,6 +798,12 @@ __device__ __forceinline__ void ring_expand_span(RingExpander &io, uint2 *tbl, u
                 hi = (start_g >= block_n || ends) ? block_n : start_g;
             }
             tbl[(lane + 1u) & 63u] = lane == 63u ? make_uint2((lo << 1) | kind, y0) : make_uint2(key, y);
+            // the table entry of the run before this lane's (lane 0: the pass's first run) and the first position
+            // of the run behind it, for the chunks in which runs start
+            const uint32_t prev_key = __builtin_amdgcn_update_dpp((lo << 1) | kind, key, 0x138, 0xf, 0xf, false);  // wave_shr:1
+            const uint32_t prev_y = __builtin_amdgcn_update_dpp(y0, y, 0x138, 0xf, 0xf, false);
+            const uint32_t next_start = __builtin_amdgcn_update_dpp(
+                0xffffffffu, key != kRingNoRun ? start : 0xffffffffu, 0x130, 0xf, 0xf, false);  // wave_shl:1
             PQ2_CLOCK_ADD(4, clock_p1);
             const uint64_t clock_ix = PQ2_CLOCK();
             // ---- index: the run that holds the first position of every chunk ---------------------------
@@ -907,36 +913,60 @@ __device__ __forceinline__ void ring_expand_span(RingExpander &io, uint2 *tbl, u
                         out[at] = (e.x & 1u) ? e.y : f;
                 }
             }
+            // the chunks in which a run starts are left to the lane of that run
             if (key != kRingNoRun) {
                 const uint32_t q = (start + mis) >> 2;
-                const int32_t p = (int32_t)(q * 4u) - (int32_t)mis;
-                const uint32_t j0 = cidx[q];
-                uint2 t[5];
+                const int32_t p = (int32_t)(q * 4u) - (int32_t)mis;  // p <= start < p + 4
+                const int32_t first_pos = max(p, (int32_t)lo), past = min(p + 4, (int32_t)hi);
+                // the usual case: the run before holds everything in front of this run's first value (its table
+                // entry came over from the lane below), and no further run starts inside the chunk
+                const bool simple = (int32_t)(prev_key >> 1) <= first_pos && next_start >= (uint32_t)past;
+                if (simple) {
+                    uint32_t f[4];
 #pragma unroll
-                for (uint32_t i = 0; i < 5u; ++i) t[i] = tbl[min(j0 + i, kRingTableRuns + 1u)];
-#pragma unroll
-                for (uint32_t i = 0; i < 5u; ++i) pin(t[i].x), pin(t[i].y);
-                uint2 cur[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const uint32_t pk = (uint32_t)max(p + k, (int32_t)lo);
-                    if (((pk << 1) | 1u) >= t[1].x) {
-#pragma unroll
-                        for (uint32_t i = 0; i < 4u; ++i) t[i] = t[i + 1u];
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t pk = (uint32_t)max(p + k, (int32_t)lo);
+                        f[k] = field_at<W>(ring, ((pk >= start ? y : prev_y) + pk * w) & bit_mask);
                     }
-                    cur[k] = t[0];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) pin(f[k]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const bool own = p + k >= (int32_t)start;
+                        const uint32_t ek = own ? key : prev_key, ey = own ? y : prev_y;
+                        if (p + k >= first_pos && p + k < past) out[p + k] = (ek & 1u) ? ey : f[k];
+                    }
+                } else {
+                    // the chunk's four positions lie in the run that holds its first position and the up to three
+                    // behind it (runs in the table hold at least one value): their entries, then the four fields
+                    const uint32_t j0 = cidx[q];
+                    uint2 t[5];  // entries j0 .. j0 + 4 (behind the table's end: the sentinel)
+#pragma unroll
+                    for (uint32_t i = 0; i < 5u; ++i) t[i] = tbl[min(j0 + i, kRingTableRuns + 1u)];
+#pragma unroll
+                    for (uint32_t i = 0; i < 5u; ++i) pin(t[i].x), pin(t[i].y);
+                    uint2 cur[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t pk = (uint32_t)max(p + k, (int32_t)lo);
+                        if (((pk << 1) | 1u) >= t[1].x) {  // one step forward is enough: the window moves up
+#pragma unroll
+                            for (uint32_t i = 0; i < 4u; ++i) t[i] = t[i + 1u];
+                        }
+                        cur[k] = t[0];
+                    }
+                    uint32_t f[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t pk = (uint32_t)max(p + k, (int32_t)lo);
+                        f[k] = field_at<W>(ring, (cur[k].y + pk * w) & bit_mask);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) pin(f[k]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (p + k >= first_pos && p + k < past) out[p + k] = (cur[k].x & 1u) ? cur[k].y : f[k];
                 }
-                uint32_t f[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const uint32_t pk = (uint32_t)max(p + k, (int32_t)lo);
-                    f[k] = field_at<W>(ring, (cur[k].y + pk * w) & bit_mask);
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) pin(f[k]);
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (p + k >= (int32_t)lo && p + k < (int32_t)hi) out[p + k] = (cur[k].x & 1u) ? cur[k].y : f[k];
             }
             PQ2_CLOCK_ADD(7, clock_st);
             // ---- next pass: run ridx + 1 + g becomes the first run -----------------------------------------

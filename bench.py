@@ -1,15 +1,26 @@
 #!/usr/bin/env python3
 """Benchmark of the device-resident hybrid-RLE / bit-packed decode.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload ...]
 
-One step = one pass of the decoder (pq2_decode_batch_device: decode_kernel, or parse + expand kernels) over one batch of
-synthetic RLE_DICTIONARY index pages already resident in HBM: `--pages` pages per GPU of 2^20 values, bit
-width 12, mixed RLE / bit-packed runs (BASELINE.json configs[1]; the default of 2048 pages per GPU is the per-GPU
-share of configs[4]).  With N > 1 the script runs under
-torch.distributed.run, one rank per GPU; every rank decodes its own shard of the global page list
-(pq2_partition_pages), there is no data-path collective, and the reported value is the whole-job rate
-(all ranks' output bytes / slowest rank's time).  Rank 0 prints one JSON line.
+One step = one pass of the decoder (pq2_decode_batch_device) over one batch of synthetic pages already resident
+in HBM.  The default workload is BASELINE.json configs[1]: RLE_DICTIONARY index pages of 2^20 values, bit width
+12, mixed RLE / bit-packed runs, 2048 pages per GPU (the per-GPU share of configs[4]), 256 distinct pages
+replicated to distinct addresses.  Other workloads (parity-test shapes of the other configs; each prints its own
+JSON line with the same fields):
+
+    --workload def          configs[2]: definition levels, bit width 1, long RLE runs, 5 % nulls
+                            (use --pages 10000 --values 65536)
+    --workload adversarial  configs[3]: alternating 1-8-value RLE runs and one-group bit-packed runs
+                            (use --pages 16 --bits 3|17|31)
+    --workload bitpacked    pages as the reference's own encoder writes them: one bit-packed run
+    --workload mixed5       configs[4]'s page mix: 75 % config-2 pages, 25 % definition-level pages of the same size
+    --workload bitunpack    configs[0]: bitpacked::Decoder<u32> over 2^20 values at every width 1..32 (and over
+                            2^26 values, where the launch no longer dominates), next to the CPU port per width
+
+With N > 1 the script runs under torch.distributed.run, one rank per GPU; every rank decodes its own shard of the
+global page list (pq2_partition_pages), there is no data-path collective, and the reported value is the whole-job
+rate (all ranks' output bytes / slowest rank's time).  Rank 0 prints one JSON line.
 """
 import argparse
 import json
@@ -39,8 +50,11 @@ def parse_args():
     ap.add_argument("--pages", type=int, default=2048, help="pages per GPU in one batch")
     ap.add_argument("--values", type=int, default=1 << 20, help="values per page")
     ap.add_argument("--bits", type=int, default=12)
-    ap.add_argument("--distinct", type=int, default=16, help="distinct generated pages (replicated on the device)")
-    ap.add_argument("--workload", default="dict", choices=["dict", "def", "adversarial", "bitpacked"])
+    ap.add_argument("--distinct", type=int, default=256,
+                    help="distinct generated pages of each kind (replicated on the device); every page has its own "
+                         "run lengths, so the header walks of a batch are not in lock-step")
+    ap.add_argument("--workload", default="dict",
+                    choices=["dict", "def", "adversarial", "bitpacked", "mixed5", "bitunpack"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-path", action="store_true",
                     help="time pq2_decode_batch_host instead (page-locked host buffers in, host buffers out: the "
@@ -54,26 +68,36 @@ def parse_args():
     return ap.parse_args()
 
 
-def make_pages(args):
-    """`distinct` different pages: list of (stream ndarray, expected values ndarray)."""
-    pages = []
-    for p in range(args.distinct):
-        if args.workload == "dict":
-            pages.append(synth.dict_page(synth.seed_for(2, p), args.values, args.bits))
-        elif args.workload == "def":
-            pages.append(synth.def_levels_page(synth.seed_for(3, p), args.values))
-        elif args.workload == "adversarial":
-            pages.append(synth.adversarial(synth.seed_for(4, p), args.values, args.bits))
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def make_pool(kind, count, values, bits):
+    """`count` different pages of one kind: list of (stream ndarray, expected values ndarray, bit width)."""
+    pool = []
+    for p in range(count):
+        if kind == "dict":
+            s, v = synth.dict_page(synth.seed_for(2, p), values, bits)
+        elif kind == "def":
+            s, v = synth.def_levels_page(synth.seed_for(3, p), values)
+            bits = 1
+        elif kind == "adversarial":
+            s, v = synth.adversarial(synth.seed_for(4, p), values, bits)
         else:  # one bit-packed run, as the reference's own encoder writes pages
             from parquet2_amd.encoding.hybrid_rle import encode_u32
-            v = synth.uniform_values(synth.seed_for(1, p), args.values, args.bits)
-            pages.append((np.frombuffer(encode_u32(v, args.bits), dtype=np.uint8), v))
-    return pages
+            v = synth.uniform_values(synth.seed_for(1, p), values, bits)
+            s = np.frombuffer(encode_u32(v, bits), dtype=np.uint8)
+        pool.append((np.ascontiguousarray(s, dtype=np.uint8), v, bits))
+    return pool
 
 
-def cpu_baseline(pages, bits, seconds, workload):
-    """The CPU oracle (plain-C port of the reference decoder) timed on this host: one thread, and all the
-    threads this box gives us, each decoding whole pages.  Also the parity checker of the sample."""
+def load_oracle():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _oracle
 
@@ -84,30 +108,35 @@ def cpu_baseline(pages, bits, seconds, workload):
     except Exception:
         path = None
         flags = "gcc -O3"
-    orc = _oracle.Oracle(path)
-    n_values = sum(len(v) for _, v in pages)
-    # parity of the oracle itself on the sample (the GPU output is compared with `values` by the caller)
-    for stream, vals in pages[:2]:
+    return _oracle.Oracle(path), flags
+
+
+def cpu_baseline(sample, seconds, what):
+    """The CPU oracle (plain-C port of the reference decoder) timed on this host: one thread, and all the
+    threads this box gives us, each decoding whole pages.  Also the parity checker of the sample.
+    sample: list of (stream, values, bits)."""
+    orc, flags = load_oracle()
+    n_values = sum(len(v) for _, v, _ in sample)
+    for stream, vals, bits in sample[:2]:
         st, out = orc.hybrid_rle_decode(stream, bits, len(vals))
         assert st == 0 and (out == vals).all(), "oracle disagrees with the generator"
-    # single thread
     t_budget = max(1.0, seconds / 2)
     best = None
     t_start = time.perf_counter()
     reps_done = 0
     while time.perf_counter() - t_start < t_budget:
-        t = sum(orc.time_hybrid_rle_decode(s, bits, len(v), 1) for s, v in pages)
+        t = sum(orc.time_hybrid_rle_decode(s, b, len(v), 1) for s, v, b in sample)
         best = t if best is None else min(best, t)
         reps_done += 1
     one = 4.0 * n_values / best / 1e9
     # all threads of our CPU share (16 on a one-GPU box), pages sharded over threads; ctypes drops the GIL
     n_thr = max(1, min(16, len(os.sched_getaffinity(0))))
     results = [0.0] * n_thr
+    reps = max(1, reps_done // 2)
 
     def work(i):
-        mine = pages[i % len(pages)]
-        reps = max(1, reps_done // 2)
-        results[i] = orc.time_hybrid_rle_decode(mine[0], bits, len(mine[1]), reps) / reps
+        s, v, b = sample[i % len(sample)]
+        results[i] = orc.time_hybrid_rle_decode(s, b, len(v), reps) / reps
 
     thr = [threading.Thread(target=work, args=(i,)) for i in range(n_thr)]
     t0 = time.perf_counter()
@@ -116,14 +145,101 @@ def cpu_baseline(pages, bits, seconds, workload):
     for t in thr:
         t.join()
     wall = time.perf_counter() - t0
-    reps = max(1, reps_done // 2)
-    many = 4.0 * sum(len(pages[i % len(pages)][1]) for i in range(n_thr)) * reps / wall / 1e9
+    many = 4.0 * sum(len(sample[i % len(sample)][1]) for i in range(n_thr)) * reps / wall / 1e9
     return {
-        "value": round(one, 3), "unit": "GB/s", "cores": 1, "kind": "port",
-        "sample": "%d %s pages x %d values, bit width %d, C port of HybridRleDecoder drained per value (%s), "
-                  "best of %d passes" % (len(pages), workload, len(pages[0][1]), bits, flags, reps_done),
+        "value": round(one, 3), "unit": "GB/s", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
+        "sample": "%d pages of the workload (%s), C port of HybridRleDecoder drained per value (%s), best of %d passes"
+                  % (len(sample), what, flags, reps_done),
         "all_threads": {"value": round(many, 3), "cores": n_thr},
     }
+
+
+def traffic_from_profiles(workload_key, kernel_name):
+    """HBM bytes of `kernel_name` per launch from the PMC passes recorded for exactly this workload under
+    profiles/ (FETCH_SIZE / WRITE_SIZE cannot be collected from inside the process): (bytes or None, source)."""
+    for name in ("r2_traffic.json", "r1_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            t = json.load(open(path))
+            if t["workload"] == workload_key and kernel_name in t:
+                e = t[kernel_name]
+                per_launch = (e["fetch_bytes_per_step"] + e["write_bytes_per_step"]) // max(e["launches_per_step"], 1)
+                return per_launch, "profiles/%s (%s: rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of an earlier run " \
+                                   "of this command; not measured in this run)" % (name, kernel_name)
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
+
+
+def bench_bitunpack(args, dev, ctx, stream):
+    """configs[0]: bitpacked::Decoder<u32>::try_new(bytes, w, N) drained, w = 1..32 (benches/decode_bitpacking.rs)."""
+    from parquet2_amd.encoding import bitpacked
+
+    results = {"small": [], "large": []}
+    cpu = []
+    orc, flags = (None, None) if args.no_cpu_baseline else load_oracle()
+    for w in range(1, 33):
+        for tag, n in (("small", 1 << 20), ("large", 1 << 26)):
+            vals = synth.uniform_values(synth.seed_for(1, w), 1 << 20, w)
+            packed = bitpacked.encode(vals, w)
+            if tag == "small":
+                # the reference's bench pattern at this width as well: parity only
+                pattern = synth.bench_pattern(n * w // 8)
+                d_pat = torch.from_numpy(np.concatenate([pattern, np.zeros(16, np.uint8)])).to(dev)
+                out = torch.zeros(n, dtype=torch.int32, device=dev)
+                ctx.bitunpack_u32_device(d_pat.data_ptr(), pattern.size, w, n, out.data_ptr(), stream)
+                if orc is not None:
+                    st, exp = orc.bitunpack_u32(pattern, w, n)
+                    assert st == 0 and (out.cpu().numpy().view(np.uint32) == exp).all(), "pattern differs at w=%d" % w
+                    cpu.append(round(4.0 * n / (orc.time_bitunpack_u32(packed, w, n, 5) / 5) / 1e9, 3))
+            reps = n >> 20
+            d_packed = torch.from_numpy(np.concatenate([np.tile(packed[:(1 << 20) * w // 8], reps),
+                                                        np.zeros(16, np.uint8)])).to(dev)
+            out = torch.zeros(n, dtype=torch.int32, device=dev)
+            ctx.bitunpack_u32_device(d_packed.data_ptr(), n * w // 8, w, n, out.data_ptr(), stream)
+            got = out.view(reps, 1 << 20)
+            expect = torch.from_numpy(vals.view(np.int32)).to(dev)
+            assert torch.equal(got[0], expect) and torch.equal(got[reps - 1], expect), "bit-unpack differs at w=%d" % w
+            for _ in range(args.warmup):
+                ctx.bitunpack_u32_device(d_packed.data_ptr(), n * w // 8, w, n, out.data_ptr(), stream)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.steps):
+                ctx.bitunpack_u32_device(d_packed.data_ptr(), n * w // 8, w, n, out.data_ptr(), stream)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / args.steps
+            results[tag].append((w, ms, 4.0 * n / ms / 1e6, (4.0 + w / 8.0) * n / ms / 1e6))
+            del d_packed, out
+    large = results["large"]
+    worst = min(large, key=lambda r: r[3])
+    total_out = sum(4.0 * (1 << 26) for _ in large)
+    total_ms = sum(r[1] for r in large)
+    line = {
+        "metric": "device-resident bit-unpack GB/s (output bytes), bitpacked::Decoder<u32>, widths 1..32",
+        "value": round(total_out / total_ms / 1e6, 2), "unit": "GB/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(total_ms, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {"workload": "bitunpack (BASELINE configs[0]): uniform values, every width 1..32; a step is one "
+                               "call per width over 2^26 values (value, roofline) -- and over 2^20 values, the "
+                               "reference bench's size, where one call is a few microseconds of launch",
+                   "gpu_2p26_values_gbs_out_by_width": [round(r[2], 1) for r in large],
+                   "gpu_2p26_values_gbs_in_plus_out_by_width": [round(r[3], 1) for r in large],
+                   "gpu_2p20_values_us_per_call_by_width": [round(r[1] * 1e3, 2) for r in results["small"]],
+                   "gpu_2p20_values_gbs_out_by_width": [round(r[2], 1) for r in results["small"]]},
+        "roofline": {"bound": "hbm", "kernel": "bitunpack_kernel", "achieved": round(worst[3], 1),
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(worst[3] / HBM_PEAK_GBS, 4), "traffic": None,
+                     "traffic_source": None,
+                     "note": "the width furthest from the roofline (w=%d); algorithmic bytes = (4 + w/8) per value; "
+                             "launch duration between events on the launch stream" % worst[0]},
+    }
+    if orc is not None:
+        line["cpu_baseline"] = {"value": round(sum(cpu) / len(cpu), 3), "unit": "GB/s", "cores": 1, "kind": "port",
+                                "cpu_model": cpu_model(),
+                                "sample": "2^20 values per width, C port of bitpacked::Decoder<u32> drained per "
+                                          "value (%s), mean over widths 1..32 of 5 passes each" % flags,
+                                "gbs_out_by_width": cpu}
+    print(json.dumps(line), flush=True)
 
 
 def main():
@@ -149,40 +265,57 @@ def main():
         sys.exit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    ctx = Context(local_rank)
+    stream = torch.cuda.current_stream().cuda_stream
 
-    pages = make_pages(args)
+    if args.workload == "bitunpack":
+        bench_bitunpack(args, dev, ctx, stream)
+        ctx.close()
+        return
+
     n = args.values
-    # global page list: world * pages pages, page g is a copy of distinct page g % distinct; rank r takes
-    # the contiguous shard pq2_partition_pages gives it
     total_pages = world * args.pages
+    distinct = max(1, min(args.distinct, total_pages))
+    # pools of distinct pages; `kind_of[g]` = pool of global page g, `slot_of[g]` = its entry of that pool
+    if args.workload == "mixed5":  # every fourth page holds definition levels, the others dictionary indices
+        pools = [make_pool("dict", distinct, n, args.bits), make_pool("def", max(1, distinct // 4), n, 1)]
+        kind_of = np.where(np.arange(total_pages) % 4 == 3, 1, 0)
+    else:
+        pools = [make_pool(args.workload, distinct, n, args.bits)]
+        kind_of = np.zeros(total_pages, dtype=np.int64)
+    slot_of = np.zeros(total_pages, dtype=np.int64)
+    for k, pool in enumerate(pools):
+        sel = np.nonzero(kind_of == k)[0]
+        slot_of[sel] = np.arange(len(sel)) % len(pool)
+    pool_base = np.cumsum([0] + [len(p) for p in pools])[:-1]
+    flat = [e for pool in pools for e in pool]
+    flat_of = pool_base[kind_of] + slot_of
+
+    # global descriptor list; rank r takes the contiguous shard pq2_partition_pages gives it
     g_descs = np.zeros(total_pages, dtype=PAGE_DESC_DTYPE)
     g_descs["num_values"] = n
+    g_descs["in_len"] = [len(flat[f][0]) for f in flat_of]
+    g_descs["num_bits"] = [flat[f][2] for f in flat_of]
     bounds = partition_pages(g_descs, world)
     lo, hi = int(bounds[rank]), int(bounds[rank + 1])
     my_pages = hi - lo
 
     # device-resident input: the distinct streams once, then one replica per page at its own address
-    stride = max(len(s) for s, _ in pages)
-    stride = (stride + 16 + 255) // 256 * 256
-    h_in = np.zeros((len(pages), stride), dtype=np.uint8)
-    for i, (s, _) in enumerate(pages):
+    stride = (max(len(s) for s, _, _ in flat) + 16 + 255) // 256 * 256
+    h_in = np.zeros((len(flat), stride), dtype=np.uint8)
+    for i, (s, _, _) in enumerate(flat):
         h_in[i, :len(s)] = s
-    d_distinct = torch.from_numpy(h_in).to(dev)
-    idx = torch.arange(lo, hi, device=dev) % len(pages)
-    d_in = d_distinct[idx].contiguous()  # [my_pages, stride]
+    d_flat = torch.from_numpy(h_in).to(dev)
+    my_flat = torch.from_numpy(flat_of[lo:hi]).to(dev)
+    d_in = d_flat[my_flat].contiguous()  # [my_pages, stride]
+    del d_flat
     d_out = torch.empty(my_pages * n, dtype=torch.int32, device=dev)
-    descs = np.zeros(my_pages, dtype=PAGE_DESC_DTYPE)
+    descs = g_descs[lo:hi].copy()
     descs["in_off"] = np.arange(my_pages, dtype=np.uint64) * stride
-    descs["in_len"] = [len(pages[(lo + i) % len(pages)][0]) for i in range(my_pages)]
-    descs["num_bits"] = args.bits if args.workload != "def" else 1
-    descs["num_values"] = n
     descs["out_off"] = np.arange(my_pages, dtype=np.uint64) * n
-    bits = int(descs["num_bits"][0])
     in_bytes_alg = int(descs["in_len"].sum())
     out_bytes = 4 * my_pages * n
-
-    ctx = Context(local_rank)
-    stream = torch.cuda.current_stream().cuda_stream
+    bits_label = "/".join(str(b) for b in sorted(set(int(b) for b in descs["num_bits"]), reverse=True))
 
     if args.host_path:  # end to end, host memory to host memory
         h_in_t = torch.empty(d_in.numel(), dtype=torch.uint8, pin_memory=True)
@@ -190,8 +323,8 @@ def main():
         h_out_t = torch.zeros(my_pages * n, dtype=torch.int32, pin_memory=True)
         h_in_np, h_out_np = h_in_t.numpy(), h_out_t.numpy().view(np.uint32)
         ctx.decode_batch_host(h_in_np, descs, my_pages * n, out=h_out_np)
-        for i in range(min(my_pages, len(pages))):
-            assert np.array_equal(h_out_np[i * n:(i + 1) * n], pages[(lo + i) % len(pages)][1]), "host path differs"
+        for i in range(min(my_pages, 2 * len(flat))):
+            assert np.array_equal(h_out_np[i * n:(i + 1) * n], flat[flat_of[lo + i]][1]), "host path differs"
         t0 = time.perf_counter()
         for _ in range(args.steps):
             _, status = ctx.decode_batch_host(h_in_np, descs, my_pages * n, out=h_out_np)
@@ -203,13 +336,14 @@ def main():
             "steps": args.steps, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "bytes_over_pcie_per_step": int(d_in.numel()) + out_bytes,
             "pcie_gbs": round((d_in.numel() + out_bytes) * args.steps / elapsed / 1e9, 2),
-            "config": {"workload": "%s: %d pages x %d values, bit width %d, page-locked host buffers" %
-                       (args.workload, my_pages, n, bits)}}), flush=True)
+            "config": {"workload": "%s: %d pages x %d values, bit width %s, page-locked host buffers" %
+                       (args.workload, my_pages, n, bits_label)}}), flush=True)
         ctx.close()
         return
 
     if args.gather_bytes:  # decode + dictionary gather, device-resident
         from parquet2_amd import DICT_REF_DTYPE
+        bits = int(descs["num_bits"][0])
         words = args.gather_bytes // 4
         table = torch.randint(-2**31, 2**31 - 1, ((1 << bits) * words,), dtype=torch.int32, device=dev)
         refs = np.zeros(my_pages, dtype=DICT_REF_DTYPE)
@@ -223,8 +357,8 @@ def main():
 
         assert (gstep(True) == 0).all()
         t2 = table.view(1 << bits, words)
-        for i in range(min(my_pages, len(pages))):
-            idx = torch.from_numpy(pages[(lo + i) % len(pages)][1].astype(np.int64)).to(dev)
+        for i in range(min(my_pages, 16)):
+            idx = torch.from_numpy(flat[flat_of[lo + i]][1].astype(np.int64)).to(dev)
             assert torch.equal(d_val.view(my_pages, n, words)[i], t2[idx]), "gathered values differ on page %d" % i
         for _ in range(args.warmup):
             gstep()
@@ -254,12 +388,15 @@ def main():
         status = step(want_status=True)
         assert (status == 0).all(), "non-OK page status"
         out2d = d_out.view(my_pages, n)
-        for i in range(min(my_pages, len(pages))):
-            expect = torch.from_numpy(pages[(lo + i) % len(pages)][1].view(np.int32)).to(dev)
-            assert torch.equal(out2d[i], expect), "GPU output differs from the expected values on page %d" % i
-        for i in range(len(pages), my_pages):
-            if i % 61 == 0 or i == my_pages - 1:
-                assert torch.equal(out2d[i], out2d[i % len(pages)]), "replica %d differs" % i
+        first_of = {}
+        for i in range(my_pages):
+            f = int(flat_of[lo + i])
+            if f not in first_of:  # the first replica of a distinct page against the generator's values ...
+                first_of[f] = i
+                expect = torch.from_numpy(flat[f][1].view(np.int32)).to(dev)
+                assert torch.equal(out2d[i], expect), "GPU output differs from the expected values on page %d" % i
+            else:  # ... every other replica against the first
+                assert torch.equal(out2d[i], out2d[first_of[f]]), "replica %d differs" % i
         expect = None
 
     for _ in range(args.warmup):
@@ -279,6 +416,7 @@ def main():
     elapsed = time.perf_counter() - t0
     parse_ms, expand_ms, batches, expand_launches = ctx.kernel_times()
     ctx.enable_profiling(False)
+    kernel_name = ctx.last_schedule()
 
     if distributed:
         rdev = dev if backend == "nccl" else torch.device("cpu")
@@ -294,41 +432,40 @@ def main():
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = total_out_bytes * args.steps / elapsed / 1e9
-        # a batch is decoded in `rounds` launches of each kernel, every launch covering 1/rounds of every page
+        # a batch is decoded in `rounds` launches of the kernel that writes the values (one, except for batches of
+        # few large pages, which go through parse_kernel + expand_kernel in rounds)
         rounds = max(expand_launches // max(batches, 1), 1)
         expand_avg_ms = expand_ms / max(expand_launches, 1)
-        # batches of many pages go through decode_kernel alone (one workgroup per page walks and expands);
-        # the context times that launch in the place of expand_kernel's
-        kernel_name = "decode_kernel" if parse_ms == 0.0 else "expand_kernel"
         bytes_per_launch = (in_bytes_alg + out_bytes) / rounds
         achieved = bytes_per_launch / (expand_avg_ms * 1e-3) / 1e9
-        # HBM bytes of that kernel from the PMC passes recorded for this workload (FETCH_SIZE / WRITE_SIZE cannot be
-        # collected from inside the process)
-        traffic = None
-        try:
-            t = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_traffic.json")))
-            if t["workload"] == {"workload": args.workload, "pages_per_gpu": args.pages, "values_per_page": n,
-                                 "num_bits": bits}:
-                e = t[kernel_name]
-                traffic = (e["fetch_bytes_per_step"] + e["write_bytes_per_step"]) // rounds
-        except (OSError, KeyError, ValueError):
-            pass
+        workload_key = {"workload": args.workload, "pages_per_gpu": args.pages, "values_per_page": n,
+                        "num_bits": args.bits if args.workload != "def" else 1}
+        traffic, traffic_source = traffic_from_profiles(workload_key, kernel_name)
+        names = {"dict": "RLE_DICTIONARY index pages (BASELINE configs[1]): %d pages/GPU x %d values, bit width %s, "
+                         "mixed RLE/bit-packed runs",
+                 "def": "definition levels (BASELINE configs[2]): %d pages/GPU x %d values, bit width %s, long RLE "
+                        "runs, 5 %% nulls in bursts",
+                 "adversarial": "adversarial short runs (BASELINE configs[3]): %d pages/GPU x %d values, bit width %s, "
+                                "alternating 1-8-value RLE runs and one-group bit-packed runs",
+                 "bitpacked": "pages of one bit-packed run (the reference's encoder): %d pages/GPU x %d values, bit "
+                              "width %s",
+                 "mixed5": "page mix of BASELINE configs[4]: %d pages/GPU x %d values, 75 %% dictionary-index pages "
+                           "and 25 %% definition-level pages (bit widths %s)"}
         result = {
             "metric": METRIC, "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {
-                "workload": "RLE_DICTIONARY index pages (BASELINE configs[1]): %d pages/GPU x %d values, "
-                            "bit width %d, mixed RLE/bit-packed runs" % (args.pages, n, bits)
-                if args.workload == "dict" else "%s: %d pages/GPU x %d values, bit width %d" %
-                (args.workload, args.pages, n, bits),
-                "pages_per_gpu": args.pages, "values_per_page": n, "num_bits": bits,
+                "workload": names[args.workload] % (args.pages, n, bits_label),
+                "pages_per_gpu": args.pages, "values_per_page": n, "num_bits": bits_label,
+                "distinct_pages": len(flat),
                 "encoded_bytes_per_gpu": in_bytes_alg, "decoded_bytes_per_gpu": out_bytes,
                 "sharding": "pages partitioned across ranks, no collective",
             },
             "roofline": {
                 "bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": int(bytes_per_launch),
                 "avg_launch_ms": round(expand_avg_ms, 4), "launches_per_step": rounds,
                 "parse_kernel_ms_per_step": round(parse_ms / max(batches, 1), 4),
@@ -336,7 +473,12 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(pages, bits, args.cpu_seconds, args.workload)
+            # a bounded sample of the same pages: about cpu_seconds of decoding
+            per_pool = max(1, 16 // len(pools))
+            sample = [e for pool in pools for e in pool[:per_pool]]
+            while len(sample) > 1 and sum(len(v) for _, v, _ in sample) > (16 << 20):
+                sample = sample[:len(sample) // 2]
+            result["cpu_baseline"] = cpu_baseline(sample, args.cpu_seconds, args.workload)
         print(json.dumps(result), flush=True)
     ctx.close()
     if distributed:

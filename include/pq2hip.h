@@ -83,6 +83,11 @@ const char *pq2_last_error(const pq2_ctx *ctx);
  * milliseconds with the number of batches and (if expand_launches is not
  * NULL) of expand launches, and resets the sums. */
 int32_t pq2_ctx_enable_profiling(pq2_ctx *ctx, int32_t on);
+/* Name of the kernel that produced the values of the last batch on this context ("ring_kernel": one
+ * workgroup per page, the stream staged once through LDS; "decode_kernel": one workgroup per page, hand-off
+ * through device memory; "expand_kernel": one wave per 4096 values behind parse_kernel; "" before the first
+ * batch).  For benchmark reports. */
+const char *pq2_ctx_last_schedule(const pq2_ctx *ctx);
 int32_t pq2_ctx_kernel_times(pq2_ctx *ctx, double *parse_ms, double *expand_ms, uint64_t *batches,
                              uint64_t *expand_launches);
 

@@ -64,6 +64,7 @@ SIGNATURES = {
     "pq2_strerror": (C.c_char_p, [C.c_int32]),
     "pq2_last_error": (C.c_char_p, [C.c_void_p]),
     "pq2_ctx_enable_profiling": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "pq2_ctx_last_schedule": (C.c_char_p, [C.c_void_p]),
     "pq2_ctx_kernel_times": (C.c_int32, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), u64p, u64p]),
     "pq2_decode_batch_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p,
                                              C.c_uint64, C.c_void_p, C.c_void_p]),
@@ -184,6 +185,10 @@ class Context:
     # ---- kernel timing ---------------------------------------------------------
     def enable_profiling(self, on=True):
         self._check(lib().pq2_ctx_enable_profiling(self._h, int(on)))
+
+    def last_schedule(self):
+        """Name of the kernel that carried the last batch's values."""
+        return lib().pq2_ctx_last_schedule(self._h).decode()
 
     def kernel_times(self):
         """(parse_ms, expand_ms, batches, expand_launches) summed since the last call."""

@@ -168,6 +168,7 @@ struct pq2_ctx {
                expand_joined[2] = {nullptr, nullptr};
     std::vector<int32_t> host_status;  // statuses decided on the host (bad num_bits)
     uint64_t last_n_pages = 0;
+    const char *last_schedule = "";  // the kernel that carried the values of the last batch
     hipStream_t last_stream = nullptr;
     bool busy = false;  // a batch may still be running on last_stream
     // optional kernel timing (pq2_ctx_enable_profiling): events around parse and expand of every batch
@@ -470,6 +471,7 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
     }
     if (ctx->profiling) ++ctx->stamped_batches;
     ctx->last_n_pages = n_pages;
+    ctx->last_schedule = ring ? "ring_kernel" : per_page ? "decode_kernel" : "expand_kernel";
     return PQ2_OK;
 }
 
@@ -567,6 +569,8 @@ const char *pq2_strerror(int32_t status) {
 }
 
 const char *pq2_last_error(const pq2_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+const char *pq2_ctx_last_schedule(const pq2_ctx *ctx) { return ctx ? ctx->last_schedule : ""; }
 
 int32_t pq2_ctx_enable_profiling(pq2_ctx *ctx, int32_t on) {
     if (!ctx) return PQ2_INVALID_PARAMETER;

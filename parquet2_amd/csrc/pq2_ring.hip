@@ -67,7 +67,10 @@ constexpr uint32_t kRingSpanValues = kRingSpanBlocks * kBlockValues;
 constexpr uint32_t kRingSpanChunks = kRingSpanValues / 4u;   // 16-byte output chunks per span
 constexpr uint32_t kRingChunkSlots = kRingSpanChunks + 8u;   // + 2 when the output is not 16-byte aligned, rounded up
 constexpr uint32_t kRingNoRun = 0xffffffffu;
-constexpr uint32_t kRingStepGroup = 5;
+#ifndef PQ2_RING_STEP_GROUP
+#define PQ2_RING_STEP_GROUP 5
+#endif
+constexpr uint32_t kRingStepGroup = PQ2_RING_STEP_GROUP;  // emission steps whose LDS reads are in flight together
 
 struct RingCtl {
     uint32_t covered;    // values covered by the published entries (kAllParsed: the page's entries are complete)

@@ -6,8 +6,9 @@ code only): mixed streams with true RLE runs of length > 1 decoded to values,
 RLE values with bits above num_bits set, the dropped header at the end of the
 stream, the min(bytes, len) clamp beyond the `small` case, hybrid streams at
 widths other than 1/2/3/10, num_values larger than the stream for w > 1, and
-every panic path.  tests/test_oracle_properties.py exercises those against an
-independent numpy model and against pyarrow-written pages.
+every panic path.  tests/test_oracle_properties.py exercises those against a
+second model written from the same reference lines, and pins the conforming
+streams among them with pages written by pyarrow (tests/golden/pyarrow_pages.json).
 """
 import numpy as np
 

@@ -292,6 +292,43 @@ def test_config3_definition_levels(ctx, oracle):
     assert (exp == expect[7]).all()
 
 
+@pytest.fixture(scope="module")
+def config3_full():
+    """10 000 distinct pages of 65 536 definition levels: the batch, and the levels it was written from."""
+    n, n_pages = 65536, 10000
+    batch = synth.PageBatch()
+    levels = np.empty(n * n_pages, dtype=np.uint32)
+    for p in range(n_pages):
+        stream, vals = synth.def_levels_page(0xC3000000 + p, n)
+        batch.add(stream, 1, n)
+        levels[p * n:(p + 1) * n] = vals
+    return batch.finish(), levels
+
+
+def test_config3_full_size(ctx, oracle, config3_full):
+    """The whole configuration: 10 000 pages x 65 536 levels of width 1 in one batch, every value compared with
+    the levels the pages were written from (on the device, in slices), a sample of pages with the oracle."""
+    import torch
+
+    (data, descs, out_values), levels = config3_full
+    n = 65536
+    assert out_values == levels.size
+    d_in = torch.from_numpy(data).cuda()
+    d_out = torch.full((out_values,), -1, dtype=torch.int32, device="cuda")
+    st = ctx.decode_batch_device(d_in.data_ptr(), d_in.numel(), descs, d_out.data_ptr(), out_values,
+                                 torch.cuda.current_stream().cuda_stream)
+    assert (st == OK).all()
+    step = 1 << 26
+    for lo in range(0, out_values, step):
+        want = torch.from_numpy(levels[lo:lo + step].view(np.int32)).cuda()
+        assert torch.equal(d_out[lo:lo + step], want), "first difference in values %d.." % lo
+    for p in (0, 4999, 9999):
+        d = descs[p]
+        st_o, exp = oracle.hybrid_rle_decode(data[int(d["in_off"]):][:int(d["in_len"])], 1, n)
+        assert st_o == OK
+        assert (d_out[int(d["out_off"]):int(d["out_off"]) + n].cpu().numpy().view(np.uint32) == exp).all()
+
+
 @pytest.mark.parametrize("w", [3, 17, 31])
 def test_config4_adversarial_short_runs(ctx, oracle, w):
     n = 1 << 20

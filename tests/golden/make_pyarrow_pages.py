@@ -178,8 +178,8 @@ def main():
     for name, arr, (defs, reps, leaves), max_def, max_rep, kind in columns(rng):
         for version in ("1.0", "2.0"):
             for use_dict in (True, False):
-                if not use_dict and name in ("opt_str", "opt_i32_few", "req_i32"):
-                    continue       # PLAIN pages are kept for the level streams of the nested columns only
+                if not use_dict and name in ("opt_str", "opt_i32_few"):
+                    continue       # these two are kept for their index streams
                 schema = pa.schema([pa.field(name, arr.type, nullable=max_def > 0)])
                 sink = io.BytesIO()
                 pq.write_table(pa.Table.from_arrays([arr], schema=schema), sink, compression="NONE",

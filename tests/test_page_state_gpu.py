@@ -222,22 +222,26 @@ def test_native_error_arms(ctx):
     # values whose length is no multiple of the type (native.rs:15-26)
     with pytest.raises(OutOfSpec):
         NativePageState.try_new(make_page(vals.tobytes()[:-1], 16, Encoding.Plain, 0), None, "<i4", ctx)
-    # index bit width above 32 and an empty values buffer (utils.rs:13-27)
+    # index bit width above 32; an empty values buffer, whose first byte the reference indexes (utils.rs:13-27)
     with pytest.raises(OutOfSpec):
         NativePageState.try_new(make_page(bytes([33, 3, 0]), 16, Encoding.RleDictionary, 0), vals, "<i4", ctx)
-    with pytest.raises(OutOfSpec):
+    with pytest.raises(ReferencePanic):
         NativePageState.try_new(make_page(b"", 16, Encoding.RleDictionary, 0), vals, "<i4", ctx)
-    # a V1 page whose level length runs past the buffer, a V2 page whose header does (src/page/mod.rs:350-411)
+    # a V1 page whose level length runs past the buffer is an error (src/page/mod.rs:350-398); a V2 page whose
+    # header's lengths do is sliced without a check (src/page/mod.rs:400-411)
     bad = DataPage(DataPageHeaderV1(16, Encoding.Plain), struct.pack("<I", 99) + b"\x03\x01",
                    Descriptor(1, 0, Repetition.Optional))
     with pytest.raises(OutOfSpec):
         NativePageState.try_new(bad, None, "<i4", ctx)
     bad = DataPage(DataPageHeaderV2(16, 40, 0, Encoding.Plain), b"\x03\x01" + vals.tobytes()[:8],
                    Descriptor(1, 0, Repetition.Optional))
-    with pytest.raises(OutOfSpec):
+    with pytest.raises(ReferencePanic):
         NativePageState.try_new(bad, None, "<i4", ctx)
-    # a level stream whose RLE run lost its value byte: the reference panics while decoding (Levels arm)
-    page = make_page(vals.tobytes(), 16, Encoding.Plain, 2, bytes([32]))
+    # a level stream of width 9 whose RLE run has one of its two value bytes: the reference panics when it
+    # reads the run (Levels arm); with none left the header is dropped and the levels read as zeros
+    assert not any(NativePageState.try_new(make_page(vals.tobytes(), 16, Encoding.Plain, 300, bytes([32])), None,
+                                           "<i4", ctx).validity.iter)
+    page = make_page(vals.tobytes(), 16, Encoding.Plain, 300, bytes([32, 1]))
     with pytest.raises(ReferencePanic):
         NativePageState.try_new(page, None, "<i4", ctx)
 

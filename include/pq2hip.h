@@ -360,12 +360,27 @@ uint64_t pq2_zigzag_leb128_encode(int64_t value, uint8_t container[10]);
 
 /* ---- multi-GPU sharding ---------------------------------------------------- */
 
-/* Splits a batch into `n_parts` contiguous page ranges balanced on output
- * bytes (pages share no state, so there is no exchange step: each rank
- * decodes pages [bounds[r], bounds[r+1]) on its own GPU).  `bounds` receives
- * n_parts + 1 page indices.  The reference delegates this to its callers
- * (README.md:107-128). */
+/* Splits a batch into `n_parts` contiguous page ranges balanced on what a page
+ * costs its GPU: the bytes it moves through HBM, in_len + 4 * num_values.
+ * Among contiguous splits the heaviest part (the one the batch waits for) is
+ * as light as it can be.  Pages share no state, so there is no exchange step:
+ * each rank decodes pages [bounds[r], bounds[r+1]) on its own GPU.  `bounds`
+ * receives n_parts + 1 page indices.  The reference delegates this to its
+ * callers (README.md:107-128: one thread per column chunk). */
 int32_t pq2_partition_pages(const pq2_page_desc *descs, uint64_t n_pages, uint32_t n_parts, uint64_t *bounds);
+
+/* One process, several GPUs: the batch of pq2_decode_batch_host split with
+ * pq2_partition_pages over `n_ctx` contexts (one per GPU, from
+ * pq2_ctx_create(device)), each driven by a host thread of its own; no data
+ * moves between the GPUs.  This is the reference's thread-per-column-chunk
+ * recipe (README.md:107-128) with GPUs in place of threads.  Page outputs
+ * must be laid out in page order (the spans of the ranges must not
+ * interleave); the values between two pages of one range are unspecified
+ * after the call.  `status` receives one status per page.  Two contexts on
+ * the same device are allowed (they share the GPU). */
+int32_t pq2_multi_decode(pq2_ctx *const *ctxs, uint32_t n_ctx, const void *h_in, uint64_t in_bytes,
+                         const pq2_page_desc *descs, uint64_t n_pages, uint32_t *h_out, uint64_t out_values,
+                         int32_t *status);
 
 /* ---- host-side page glue (no device work) ---------------------------------- */
 

@@ -6,6 +6,7 @@ include/pq2hip.h (parquet2_amd/lib/libpq2hip.so); this package is the host-side
 mirror of the reference's module tree.  There is no CPU decode path.
 """
 from . import deserialize, encoding, error, indexes, page, read  # noqa: F401
-from ._lib import (BLOCK_VALUES, DICT_REF_DTYPE, INTERVAL_DTYPE, PAGE_DESC_DTYPE, RAW_DICT_INDICES, RAW_PAGE_DTYPE, Context, default_context, lib, partition_pages)  # noqa: F401
+from ._lib import (BLOCK_VALUES, DICT_REF_DTYPE, INTERVAL_DTYPE, PAGE_DESC_DTYPE, RAW_DICT_INDICES, RAW_PAGE_DTYPE, Context, default_context, lib, multi_decode, page_costs,
+                   partition_pages)  # noqa: F401
 
 __version__ = "0.1.0"

@@ -102,6 +102,8 @@ SIGNATURES = {
     "pq2_zigzag_leb128_decode": (C.c_int32, [C.c_void_p, C.c_uint64, C.POINTER(C.c_int64), u64p]),
     "pq2_zigzag_leb128_encode": (C.c_uint64, [C.c_int64, u8p]),
     "pq2_partition_pages": (C.c_int32, [C.c_void_p, C.c_uint64, C.c_uint32, u64p]),
+    "pq2_multi_decode": (C.c_int32, [C.POINTER(C.c_void_p), C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+                                     C.c_void_p, C.c_uint64, C.c_void_p]),
     "pq2_ceil8": (C.c_uint64, [C.c_uint64]),
     "pq2_get_length": (C.c_int32, [C.c_void_p, C.c_uint64, u64p]),
     "pq2_get_bit_width": (C.c_uint32, [C.c_int16]),
@@ -367,8 +369,34 @@ def decode_batch_device_noalloc(device_id, d_in_ptr, in_bytes, d_descs_ptr, n_pa
         raise_for_status(st, "pq2_decode_batch_device_noalloc: " + lib().pq2_strerror(st).decode())
 
 
+def multi_decode(contexts, data, descs, out_values=None, out=None):
+    """pq2_multi_decode: one batch over several contexts (one per GPU), a host thread each.  Returns
+    (values ndarray of uint32, statuses ndarray of int32)."""
+    data = as_u8(data)
+    descs = np.ascontiguousarray(descs, dtype=PAGE_DESC_DTYPE)
+    if out_values is None:
+        out_values = int((descs["out_off"] + descs["num_values"]).max()) if len(descs) else 0
+    if out is None:
+        out = np.zeros(out_values, dtype=np.uint32)
+    assert out.dtype == np.uint32 and out.flags.c_contiguous and out.size >= out_values
+    status = np.zeros(len(descs), dtype=np.int32)
+    handles = (C.c_void_p * len(contexts))(*[c._h for c in contexts])
+    st = lib().pq2_multi_decode(handles, len(contexts), ptr(data), data.size, ptr(descs), len(descs), ptr(out),
+                                out_values, ptr(status))
+    if st != OK:
+        msg = b"; ".join(lib().pq2_last_error(c._h) or b"" for c in contexts).decode()
+        raise_for_status(st, "pq2_multi_decode: " + msg)
+    return out, status
+
+
+def page_costs(descs):
+    """What pq2_partition_pages balances: the bytes a page moves through HBM."""
+    descs = np.ascontiguousarray(descs, dtype=PAGE_DESC_DTYPE)
+    return descs["in_len"].astype(np.int64) + 4 * descs["num_values"].astype(np.int64)
+
+
 def partition_pages(descs, n_parts):
-    """Contiguous page ranges balanced on output bytes: returns n_parts + 1 bounds."""
+    """Contiguous page ranges balanced on page cost (stream bytes + value bytes): returns n_parts + 1 bounds."""
     descs = np.ascontiguousarray(descs, dtype=PAGE_DESC_DTYPE)
     bounds = np.zeros(n_parts + 1, dtype=np.uint64)
     st = lib().pq2_partition_pages(ptr(descs), len(descs), n_parts, bounds.ctypes.data_as(u64p))

@@ -15,6 +15,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -1188,22 +1189,127 @@ int32_t pq2_delta_bitpacked_decode_host(pq2_ctx *ctx, const void *values, uint64
     return PQ2_OK;
 }
 
+// What a page costs its GPU: the bytes it moves through HBM, stream in and values out.
+static inline uint64_t page_cost(const pq2_page_desc &d) { return uint64_t(d.in_len) + d.num_values * sizeof(uint32_t); }
+
 int32_t pq2_partition_pages(const pq2_page_desc *descs, uint64_t n_pages, uint32_t n_parts, uint64_t *bounds) {
     if (n_parts == 0 || !bounds || (n_pages && !descs)) return PQ2_INVALID_PARAMETER;
     unsigned __int128 total = 0;
-    for (uint64_t i = 0; i < n_pages; ++i) total += descs[i].num_values;
-    // page i goes to the part in which the midpoint of its output range falls; parts stay contiguous
-    bounds[0] = 0;
-    uint64_t page = 0;
-    unsigned __int128 before = 0;
-    for (uint32_t r = 1; r <= n_parts; ++r) {
-        const unsigned __int128 target2 = total * 2 * r / n_parts;  // twice the cumulative target
-        while (page < n_pages && before * 2 + descs[page].num_values <= target2) {
-            before += descs[page].num_values;
-            ++page;
-        }
-        bounds[r] = (r == n_parts) ? n_pages : page;
+    uint64_t largest = 0;
+    for (uint64_t i = 0; i < n_pages; ++i) {
+        total += page_cost(descs[i]);
+        largest = std::max(largest, page_cost(descs[i]));
     }
+    // first cut: page i goes to the part in which the midpoint of its cost range falls
+    std::vector<uint64_t> even(n_parts + 1, 0);
+    {
+        uint64_t page = 0;
+        unsigned __int128 before = 0;
+        for (uint32_t r = 1; r <= n_parts; ++r) {
+            const unsigned __int128 target2 = total * 2 * r / n_parts;  // twice the cumulative target
+            while (page < n_pages && before * 2 + page_cost(descs[page]) <= target2) {
+                before += page_cost(descs[page]);
+                ++page;
+            }
+            even[r] = (r == n_parts) ? n_pages : page;
+        }
+    }
+    auto heaviest = [&](const std::vector<uint64_t> &b) {
+        unsigned __int128 worst = 0;
+        for (uint32_t r = 0; r < n_parts; ++r) {
+            unsigned __int128 c = 0;
+            for (uint64_t i = b[r]; i < b[r + 1]; ++i) c += page_cost(descs[i]);
+            worst = std::max(worst, c);
+        }
+        return worst;
+    };
+    // second cut: the smallest limit under which a greedy fill needs no more than n_parts contiguous parts
+    // (bisection on the limit); it is optimal for the heaviest part, the one the batch waits for
+    auto fill = [&](unsigned __int128 limit, std::vector<uint64_t> *b) {
+        uint32_t part = 1;
+        unsigned __int128 c = 0;
+        for (uint64_t i = 0; i < n_pages; ++i) {
+            const uint64_t w = page_cost(descs[i]);
+            if (c + w > limit && c > 0) {
+                if (part == n_parts) return false;
+                if (b) (*b)[part] = i;
+                ++part;
+                c = 0;
+            }
+            c += w;
+        }
+        if (b)
+            for (; part <= n_parts; ++part) (*b)[part] = n_pages;
+        return true;
+    };
+    unsigned __int128 lo = std::max<unsigned __int128>(largest, (total + n_parts - 1) / n_parts), hi = total;
+    while (lo < hi) {
+        const unsigned __int128 mid = lo + (hi - lo) / 2;
+        if (fill(mid, nullptr)) hi = mid; else lo = mid + 1;
+    }
+    std::vector<uint64_t> tight(n_parts + 1, 0);
+    fill(lo, &tight);
+    const std::vector<uint64_t> &best = heaviest(even) <= heaviest(tight) ? even : tight;
+    for (uint32_t r = 0; r <= n_parts; ++r) bounds[r] = best[r];
+    return PQ2_OK;
+}
+
+int32_t pq2_multi_decode(pq2_ctx *const *ctxs, uint32_t n_ctx, const void *h_in, uint64_t in_bytes,
+                         const pq2_page_desc *descs, uint64_t n_pages, uint32_t *h_out, uint64_t out_values,
+                         int32_t *status) {
+    if (!ctxs || n_ctx == 0 || (n_pages && (!descs || !status))) return PQ2_INVALID_PARAMETER;
+    for (uint32_t r = 0; r < n_ctx; ++r)
+        if (!ctxs[r]) return PQ2_INVALID_PARAMETER;
+    for (uint64_t i = 0; i < n_pages; ++i) {
+        const pq2_page_desc &d = descs[i];
+        if (d.in_off > in_bytes || d.in_len > in_bytes - d.in_off)
+            return fail(ctxs[0], PQ2_INVALID_PARAMETER, "page stream outside the input buffer");
+        if (d.out_off > out_values || d.num_values > out_values - d.out_off)
+            return fail(ctxs[0], PQ2_INVALID_PARAMETER, "page output outside the output buffer");
+    }
+    std::vector<uint64_t> bounds(n_ctx + 1, 0);
+    int32_t st = pq2_partition_pages(descs, n_pages, n_ctx, bounds.data());
+    if (st != PQ2_OK) return st;
+    struct Span { uint64_t in_lo, in_hi, out_lo, out_hi; };
+    std::vector<Span> spans(n_ctx, Span{in_bytes, 0, out_values, 0});
+    for (uint32_t r = 0; r < n_ctx; ++r)
+        for (uint64_t i = bounds[r]; i < bounds[r + 1]; ++i) {
+            Span &s = spans[r];
+            s.in_lo = std::min(s.in_lo, descs[i].in_off);
+            s.in_hi = std::max(s.in_hi, descs[i].in_off + descs[i].in_len);
+            if (descs[i].num_values == 0) continue;
+            s.out_lo = std::min(s.out_lo, descs[i].out_off);
+            s.out_hi = std::max(s.out_hi, descs[i].out_off + descs[i].num_values);
+        }
+    // every GPU copies the span its pages cover back in one piece: the spans must not interleave
+    for (uint32_t a = 0; a < n_ctx; ++a)
+        for (uint32_t b = a + 1; b < n_ctx; ++b)
+            if (spans[a].out_lo < spans[a].out_hi && spans[b].out_lo < spans[b].out_hi &&
+                spans[a].out_lo < spans[b].out_hi && spans[b].out_lo < spans[a].out_hi)
+                return fail(ctxs[0], PQ2_INVALID_PARAMETER, "page outputs are not laid out in page order");
+    std::vector<int32_t> result(n_ctx, PQ2_OK);
+    // one host thread per context: each drives the three-lane host path of its own GPU over its page range,
+    // on buffers rebased to the span of that range; nothing is exchanged between the GPUs
+    auto work = [&](uint32_t r) {
+        const uint64_t first = bounds[r], last = bounds[r + 1];
+        if (first == last) return;
+        Span s = spans[r];
+        if (s.out_lo > s.out_hi) s.out_lo = s.out_hi = 0;  // only pages without values
+        std::vector<pq2_page_desc> mine(descs + first, descs + last);
+        for (pq2_page_desc &d : mine) {
+            d.in_off -= s.in_lo;
+            d.out_off = d.num_values ? d.out_off - s.out_lo : 0;
+        }
+        result[r] = pq2_decode_batch_host(ctxs[r], static_cast<const uint8_t *>(h_in) + s.in_lo, s.in_hi - s.in_lo,
+                                          mine.data(), mine.size(), h_out + s.out_lo, s.out_hi - s.out_lo,
+                                          status + first);
+    };
+    std::vector<std::thread> threads;
+    for (uint32_t r = 1; r < n_ctx; ++r) threads.emplace_back(work, r);
+    work(0);
+    for (std::thread &t : threads) t.join();
+    for (uint32_t r = 0; r < n_ctx; ++r)
+        if (result[r] != PQ2_OK) return result[r];
     return PQ2_OK;
 }
 

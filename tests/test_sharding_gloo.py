@@ -15,7 +15,7 @@ WORKER = textwrap.dedent("""
     import torch
     import torch.distributed as dist
     sys.path.insert(0, %r)
-    from parquet2_amd import PAGE_DESC_DTYPE, partition_pages
+    from parquet2_amd import PAGE_DESC_DTYPE, page_costs, partition_pages
 
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -23,8 +23,13 @@ WORKER = textwrap.dedent("""
     descs = np.zeros(301, dtype=PAGE_DESC_DTYPE)
     descs["num_values"] = rng.integers(1, 1 << 20, len(descs))
     descs["num_values"][::7] = 0                         # empty pages take part too
+    descs["in_len"] = descs["num_values"] * rng.integers(1, 33, len(descs)) // 8
     bounds = partition_pages(descs, world)
     lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    cost = page_costs(descs)
+    loads = [None] * world
+    dist.all_gather_object(loads, int(cost[lo:hi].sum()))
+    assert sum(loads) == int(cost.sum()) and max(loads) <= cost.sum() / world + cost.max()
     mine = int(descs["num_values"][lo:hi].sum()) * 4
     tot = torch.tensor([float(mine)], dtype=torch.float64)
     dist.all_reduce(tot, op=dist.ReduceOp.SUM)

@@ -47,6 +47,12 @@ int32_t pq2_noalloc_setup(int32_t device, uint8_t **out);  // pq2_noalloc.hip
 hipError_t pq2_launch_ring(const void *pages, uint32_t n_pages, int32_t *status, uint32_t *cu_tickets, uint32_t max_bits,
                            const uint32_t *tile_mask, hipStream_t stream);  // pq2_ring.hip
 uint32_t pq2_ring_ticket_bytes();
+uint32_t pq2_scout_tile_bytes();  // pq2_scout.hip
+size_t pq2_scout_table_bytes(uint64_t n_stiles);
+size_t pq2_scout_words_bytes(uint64_t n_stiles, uint64_t n_pages);
+hipError_t pq2_launch_scout(const void *pages, const void *spages, uint32_t n_pages, uint32_t n_stiles, void *table,
+                            void *words, void *resume, uint32_t *tile_page, uint32_t *run_pos, int32_t *status, void *state,
+                            uint32_t max_bits, hipStream_t stream);
 }
 
 namespace {
@@ -57,6 +63,10 @@ constexpr uint32_t kRounds = 4;          // must match pq2::kRounds
 constexpr uint64_t kMinRoundedTiles = 16384;  // batches below 64 Mi values are decoded in one round
 constexpr size_t kParseStateBytes = 16;  // sizeof(pq2::ParseState)
 constexpr uint64_t kFusedMinPages = 64;  // batches of at least this many pages take one workgroup per page
+
+struct ScoutPage {  // must match pq2::ScoutPage
+    uint32_t tile_base, n_tiles;
+};
 
 struct PageDev {  // must match pq2::PageDev
     uint64_t in_addr;
@@ -139,6 +149,7 @@ struct pq2_ctx {
     bool meta_in_flight = false;
     DevBuf d_meta, d_status, d_resume, d_tile_page, d_run_pos, d_state;
     DevBuf d_tickets;  // decode_kernel's per-compute-unit counters (zeroed once; only their low bits matter)
+    DevBuf d_scout_table, d_scout_words;  // the scout kernels' tables and per-tile words
     // pq2_decode_dict_batch_device: the decoded indices, and the per-page gather descriptors (page-locked + device)
     DevBuf d_indices, d_gather;
     void *h_gather = nullptr;
@@ -158,7 +169,9 @@ struct pq2_ctx {
     // kRing: ring_kernel, one workgroup per page like kPerPage, but the stream is staged once through an LDS ring
     // that the walking wave fills and all four waves read, and nothing passes through device memory on its way
     // from the walk to the expansion (PQ2_MODE=ring; what kAuto picks for batches of many pages).
-    enum Mode { kAuto, kPerPage, kPerTile, kRing } mode = kAuto;
+    // kScout: the scout kernels walk the headers of all pages in parallel over tiles of the streams, then
+    // expand_kernel in one round (PQ2_MODE=scout; what kAuto picks for batches of few pages).
+    enum Mode { kAuto, kPerPage, kPerTile, kRing, kScout } mode = kAuto;
     bool one_expand_stream = true;  // the expand launches of a batch follow each other (PQ2_EXPAND_STREAMS=2: they take turns on two streams)
     bool split_given = false;       // PQ2_ROUND_SPLIT was set
     // rounds: parse_kernel of round r + 1 runs on parse_stream while expand_kernel of round r runs on expand_stream
@@ -282,7 +295,9 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
     // the page descriptors and, behind them, the tile mask of a selected-rows batch
     const size_t pages_bytes = n_pages * sizeof(PageDev);
     const size_t mask_bytes = mask ? mask->words.size() * sizeof(uint32_t) : 0;
-    const size_t meta_bytes = pages_bytes + mask_bytes;
+    // ... and, for the scout kernels, where every page's stream tiles begin
+    const size_t scout_at = (pages_bytes + mask_bytes + 7) & ~size_t(7);
+    const size_t meta_bytes = scout_at + n_pages * sizeof(ScoutPage);
     int32_t st = reserve_pinned(ctx, meta_bytes);
     if (st) return st;
     if (ctx->meta_in_flight) {  // the previous batch's upload still reads the pinned block
@@ -327,10 +342,13 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
     // enough pages to fill the GPU with one workgroup each: the per-page kernel has every walk running from the
     // start, nothing of a page waits for other pages, and the stream comes out of the cache the second time it is
     // read; fewer pages: the tiles of all pages share the whole GPU
-    const bool ring = ctx->mode == pq2_ctx::kRing || (ctx->mode == pq2_ctx::kAuto && n_pages >= kFusedMinPages);
+    // few pages: no page's walk has another page's expansion to hide behind, so the walk itself is spread over
+    // the GPU (not where the streams' addresses are only known on the device)
+    const bool scout = !front && (ctx->mode == pq2_ctx::kScout || (ctx->mode == pq2_ctx::kAuto && n_pages < kFusedMinPages));
+    const bool ring = !scout && (ctx->mode == pq2_ctx::kRing || (ctx->mode == pq2_ctx::kAuto && n_pages >= kFusedMinPages));
     const bool per_page = ring || ctx->mode == pq2_ctx::kPerPage;
     // tiles are numbered round-major: all tiles of round 0 of all pages, then round 1, ...
-    const bool split = !per_page && tiles >= ctx->min_rounded_tiles;
+    const bool split = !per_page && !scout && tiles >= ctx->min_rounded_tiles;
     // Nothing hides the parse of the first part, and the walk of a page takes the same time whatever the batch
     // holds while the expansion grows with it: the larger the batch, the smaller the first part.
     double round_split[kRounds - 1];
@@ -369,6 +387,23 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
         }
     }
 
+    // stream tiles of the scout kernels: a-offsets [0, delta + in_len) of every page that has headers to walk
+    uint64_t stiles = 0;
+    if (scout) {
+        ScoutPage *sp = reinterpret_cast<ScoutPage *>(static_cast<uint8_t *>(ctx->h_meta) + scout_at);
+        const uint64_t tile_bytes = pq2_scout_tile_bytes();
+        for (uint64_t i = 0; i < n_pages; ++i) {
+            const PageDev &p = pages[i];
+            const bool walk = p.num_values > 0 && p.num_bits > 0 && p.num_bits <= 32 && p.in_len > 0;
+            const uint64_t t = walk ? ((p.in_addr & 15u) + uint64_t(p.in_len) + tile_bytes - 1) / tile_bytes : 0;
+            sp[i].tile_base = static_cast<uint32_t>(stiles);
+            sp[i].n_tiles = static_cast<uint32_t>(t);
+            stiles += t;
+            if (stiles > 0x7fffffffull) return fail(ctx, PQ2_INVALID_PARAMETER, "batch too large for one launch");
+        }
+        if ((st = reserve(ctx, ctx->d_scout_table, std::max<size_t>(pq2_scout_table_bytes(stiles), 16)))) return st;
+        if ((st = reserve(ctx, ctx->d_scout_words, pq2_scout_words_bytes(stiles, n_pages)))) return st;
+    }
     if ((st = reserve(ctx, ctx->d_meta, meta_bytes))) return st;
     if ((st = reserve(ctx, ctx->d_status, n_pages * sizeof(int32_t)))) return st;
     if (!ring) {  // what the header walk hands to the expansion through device memory
@@ -445,6 +480,21 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
             return st;
         rounds = 0;
     }
+    if (scout) {
+        if ((st = stamped(false, stream, [&] {
+                 return pq2_launch_scout(d_pages, static_cast<const uint8_t *>(ctx->d_meta.ptr) + scout_at,
+                                         static_cast<uint32_t>(n_pages), static_cast<uint32_t>(stiles),
+                                         ctx->d_scout_table.ptr, ctx->d_scout_words.ptr, ctx->d_resume.ptr, d_tile_page,
+                                         d_run_pos, d_status, ctx->d_state.ptr, max_bits, stream);
+             })))
+            return st;
+        if ((st = stamped(true, stream, [&] {
+                 return pq2_launch_expand(d_pages, d_tile_page, 0u, static_cast<uint32_t>(tiles), ctx->d_resume.ptr,
+                                          d_run_pos, 0u, max_bits, d_tile_mask, stream);
+             })))
+            return st;
+        rounds = 0;
+    }
     for (uint32_t r = 0; r < rounds; ++r) {
         if ((st = stamped(false, ps, [&] {
                  return pq2_launch_parse(d_pages, static_cast<uint32_t>(n_pages), ctx->d_resume.ptr, d_tile_page,
@@ -472,7 +522,7 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
     }
     if (ctx->profiling) ++ctx->stamped_batches;
     ctx->last_n_pages = n_pages;
-    ctx->last_schedule = ring ? "ring_kernel" : per_page ? "decode_kernel" : "expand_kernel";
+    ctx->last_schedule = ring ? "ring_kernel" : per_page ? "decode_kernel" : scout ? "scout+expand_kernel" : "expand_kernel";
     return PQ2_OK;
 }
 
@@ -510,6 +560,7 @@ int32_t pq2_ctx_create(int32_t device_id, pq2_ctx **out) {
         if (std::strcmp(v, "page") == 0) ctx->mode = pq2_ctx::kPerPage;
         if (std::strcmp(v, "tile") == 0) ctx->mode = pq2_ctx::kPerTile;
         if (std::strcmp(v, "ring") == 0) ctx->mode = pq2_ctx::kRing;
+        if (std::strcmp(v, "scout") == 0) ctx->mode = pq2_ctx::kScout;
     }
     if (const char *v = std::getenv("PQ2_ROUND_SPLIT")) {
         double a = 0, b = 0, c = 0;
@@ -533,7 +584,7 @@ int32_t pq2_ctx_destroy(pq2_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     for (DevBuf *b : {&ctx->d_meta, &ctx->d_status, &ctx->d_resume, &ctx->d_tile_page, &ctx->d_run_pos, &ctx->d_state,
-                      &ctx->d_tickets, &ctx->d_indices, &ctx->d_gather, &ctx->d_in, &ctx->d_out})
+                      &ctx->d_tickets, &ctx->d_scout_table, &ctx->d_scout_words, &ctx->d_indices, &ctx->d_gather, &ctx->d_in, &ctx->d_out})
         if (b->ptr) (void)hipFree(b->ptr);
     for (hipStream_t s : {ctx->parse_stream, ctx->expand_stream[0], ctx->expand_stream[1]})
         if (s) (void)hipStreamDestroy(s);

@@ -1,0 +1,595 @@
+// scout kernels: the header walk of a page spread over the whole GPU (gfx950 / MI355X).
+//
+// Where a run header lies is known only once the header before it is decoded
+// (src/encoding/hybrid_rle/decoder.rs:30-64), so one wave per page walks a chain (parse_kernel, decode_kernel,
+// ring_kernel).  A batch of few pages leaves most of the GPU idle during that walk, and a page whose runs are
+// short is nothing but walk.  Here the stream of every page is cut into tiles of 2 KiB (a-offsets
+// [t * 2048, (t + 1) * 2048)) and the walk is done in steps that are parallel over all tiles of the batch:
+//
+//   table    for EVERY byte offset of a tile, as if a header began there: where the chain that starts there leaves
+//            the tile.  Lane l works backwards through the 32 offsets of segment l (the bytes in registers, the
+//            results in LDS); a pass over the segments from the last to the first then extends every entry to the
+//            end of the tile.  Everything unusual (a varint of three or more bytes, a run that passes the end of
+//            the stream or reaches further than 32 KiB from the tile) is an escape that names the header, which
+//            is then decoded exactly by whoever gets there.  2 bytes per stream byte, written once.
+//   resolve  one workgroup per page: every tile starts with a guess of where it is entered (its first byte), and
+//            each round looks up, for all tiles at once, where the chain from that entry leaves the tile, marks the
+//            tiles that the chain from the page's first byte reaches (pointer doubling over the tiles) and hands
+//            each reached tile's exit to the tile it lands in.  The page's first tile is right from the start, so
+//            every round makes at least one more tile right; as chains that start at different offsets fall into
+//            step after a few headers, two or three rounds do for real data.  The result is exact either way: it
+//            is the fixed point in which every reached tile is entered where its predecessor leaves.
+//   count    one wave per reached tile walks the tile's part of the chain (the chase loop of parse_kernel, out of
+//            LDS), sums the values its runs hold and lists the runs that hold any (2 bytes per run, over the
+//            tile's table, which nobody needs any more).
+//   scan     one workgroup per page: prefix sums of the tiles' values and runs; the tile in which the page's last
+//            value lies (or the chain ends) is the one that closes the page.
+//   place    one wave per reached tile: lane r decodes listed run r, a prefix sum places it, and the wave writes
+//            what parse_kernel writes -- the header-position list and the Resume entries -- for expand_kernel.
+//
+// Reference semantics are those of parse_page (pq2_kernels.hip): the same decode_run, the same clamps, the same
+// statuses.
+#include "pq2_device.h"
+
+namespace pq2 {
+
+constexpr uint32_t kScoutTile = 2048;                       // stream bytes per tile
+constexpr uint32_t kScoutSeg = 32;                          // offsets per lane
+constexpr uint32_t kScoutRow = 66;                          // table entries per row: 64 lanes + 2 (odd dword stride)
+constexpr uint32_t kScoutTable = kScoutSeg * kScoutRow;     // entries (of 2 bytes) per tile
+constexpr uint32_t kScoutEsc = 0x8000u;                     // entry: "decode the header at tile offset (entry & 0x7fff)"
+constexpr uint32_t kScoutNone = 0xffffffffu;                // a tile the chain does not enter / a chain that has ended
+constexpr uint32_t kScoutLdsTiles = 2048;                   // pages of up to this many tiles are resolved in LDS
+constexpr uint32_t kScoutWin = kScoutTile + 64u;            // bytes of a tile the chase may touch
+constexpr uint32_t kScoutPanic = 0x80000000u, kScoutTerm = 0x40000000u, kScoutBad = 0x20000000u;
+constexpr uint32_t kScoutRunsMask = 0x1fffffffu;
+constexpr uint32_t kValueCap = 0x7fffffffu;
+
+struct ScoutPage {
+    uint32_t tile_base;  // batch-wide number of the page's first stream tile
+    uint32_t n_tiles;    // stream tiles of the page (0: nothing to walk)
+};
+struct ScoutFin {
+    uint32_t tile;   // the page's tile that closes the page
+    uint32_t flags;  // kScoutPanic | kScoutBad
+};
+// per stream tile (arrays of n_stiles words each, in this order, in one allocation)
+struct ScoutTiles {
+    uint32_t *page, *entry, *exit, *vals, *runs, *base_vals, *base_runs;
+};
+__device__ __forceinline__ ScoutTiles scout_tiles(uint32_t *base, uint32_t n_stiles) {
+    ScoutTiles t;
+    t.page = base;
+    t.entry = base + (size_t)n_stiles;
+    t.exit = base + 2 * (size_t)n_stiles;
+    t.vals = base + 3 * (size_t)n_stiles;
+    t.runs = base + 4 * (size_t)n_stiles;
+    t.base_vals = base + 5 * (size_t)n_stiles;
+    t.base_runs = base + 6 * (size_t)n_stiles;
+    return t;
+}
+__device__ __forceinline__ uint32_t table_slot(uint32_t off) { return (off & 31u) * kScoutRow + (off >> 5); }
+
+// ---------------------------------------------------------------------------
+// map: which page a stream tile belongs to
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void scout_map_kernel(const ScoutPage *__restrict__ sp, uint32_t n_pages,
+                                                        uint32_t *__restrict__ tiles, uint32_t n_stiles) {
+    const uint32_t page = blockIdx.x;
+    if (page >= n_pages) return;
+    const ScoutPage s = sp[page];
+    const ScoutTiles t = scout_tiles(tiles, n_stiles);
+    for (uint32_t k = threadIdx.x; k < s.n_tiles; k += 256u) t.page[s.tile_base + k] = page;
+}
+
+// ---------------------------------------------------------------------------
+// table
+// ---------------------------------------------------------------------------
+// Lane l: for every offset i of segment l of the tile at a-offset t0, where the chain of headers that starts at
+// i leaves the segment -- a tile offset >= 32 (l + 1), or an escape -- into tbl[i * kScoutRow + l].
+__device__ __forceinline__ void scout_segments(const PageDev &pg, const uint32_t t0, uint16_t *tbl, const uint32_t lane) {
+    const uint32_t delta = (uint32_t)(pg.in_addr & 15u);
+    const uint32_t end = delta + pg.in_len;
+    const uint32_t w = pg.num_bits;
+    const uint32_t rb = ceil8(w);
+    const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(pg.in_addr - delta, (end + 3u) & ~3u);
+    const uint32_t seg_rel = lane * kScoutSeg;
+    const uint32_t seg_a = t0 + seg_rel;
+    const u32x4 lo4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, seg_a, 0, 0);
+    const u32x4 hi4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, seg_a + 16u, 0, 0);
+    const uint32_t d8 = __builtin_amdgcn_raw_buffer_load_b32(rsrc, seg_a + 32u, 0, 0);
+    const uint32_t d[9] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w, d8};
+#pragma unroll
+    for (int i = (int)kScoutSeg - 1; i >= 0; --i) {
+        const uint32_t b0 = (d[i >> 2] >> ((i & 3) * 8)) & 0xffu;
+        const uint32_t b1 = (d[(i + 1) >> 2] >> (((i + 1) & 3) * 8)) & 0xffu;
+        const bool two = (b0 & 0x80u) != 0u;
+        const uint32_t ind = two ? ((b0 & 0x7fu) | (b1 << 7)) : b0;  // uleb128.rs:3-23, one or two bytes
+        const uint32_t c = two ? 2u : 1u;
+        const uint32_t body = (ind & 1u) ? (ind >> 1) * w : rb;      // decoder.rs:48-63
+        const uint32_t q = seg_a + (uint32_t)i + c;                  // the byte behind the header
+        const uint32_t nxt = (uint32_t)i + c + body;                 // the next header, from the segment's start
+        const uint32_t far = seg_rel + nxt;                          // ... from the tile's start
+        // the short path of decode_run: a header of one or two bytes whose run lies inside the stream
+        const bool plain = !(two && (b1 & 0x80u)) && q < end && body <= end - q && far < kScoutEsc;
+        const uint32_t inside = tbl[(nxt & 31u) * kScoutRow + lane];  // where the chain from nxt leaves (if nxt < 32)
+        uint32_t v = nxt < kScoutSeg ? inside : far;
+        if (!plain) v = kScoutEsc | (seg_rel + (uint32_t)i);
+        tbl[(uint32_t)i * kScoutRow + lane] = (uint16_t)v;
+    }
+}
+
+// One wave per tile, four tiles per workgroup.
+__global__ __launch_bounds__(256) void scout_table_kernel(const PageDev *__restrict__ pages,
+                                                          const ScoutPage *__restrict__ sp, uint32_t *__restrict__ tiles,
+                                                          uint16_t *__restrict__ table, uint32_t n_stiles) {
+    __shared__ __attribute__((aligned(16))) uint16_t lds[4][kScoutTable];
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t g = blockIdx.x * 4u + wave;
+    if (g >= n_stiles) return;
+    const ScoutTiles t = scout_tiles(tiles, n_stiles);
+    const uint32_t page = __builtin_amdgcn_readfirstlane(t.page[g]);
+    const PageDev pg = pages[page];
+    const uint32_t t0 = (g - __builtin_amdgcn_readfirstlane(sp[page].tile_base)) * kScoutTile;
+    uint16_t *const tbl = lds[wave];
+    scout_segments(pg, t0, tbl, lane);
+    wave_sync();
+    // From the last segment but one to the first: an entry that leaves its segment inside the tile takes over the
+    // entry of the offset it lands on, which is final already (that offset lies in a later segment).
+    for (int s = 62; s >= 0; --s) {
+        if (lane < kScoutSeg) {
+            const uint32_t at = lane * kScoutRow + (uint32_t)s;
+            const uint32_t v = tbl[at];
+            if (v < kScoutTile) tbl[at] = tbl[table_slot(v)];
+        }
+        wave_sync();
+    }
+    // the table as it lies in LDS: kScoutTable * 2 = 4224 bytes = 264 pieces of 16
+    u32x4 *const dst = (u32x4 *)(table + (size_t)g * kScoutTable);
+    const u32x4 *const src = (const u32x4 *)tbl;
+#pragma unroll
+    for (uint32_t i = 0; i < 5; ++i) {
+        const uint32_t at = i * 64u + lane;
+        if (at < kScoutTable * 2u / 16u) dst[at] = src[at];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// resolve
+// ---------------------------------------------------------------------------
+// Where the chain that enters a tile at a-offset x leaves that tile: the a-offset of the first header in a later
+// tile, or kScoutNone if the chain ends first (end of the stream, or a header on which the reference panics).
+__device__ __forceinline__ uint32_t scout_leave(const PageDev &pg, const __amdgpu_buffer_rsrc_t rsrc, const uint32_t end,
+                                                const uint16_t *__restrict__ page_table, uint32_t x) {
+    const uint32_t tile = x / kScoutTile;
+    auto rd = [&](uint32_t a) -> uint32_t { return __builtin_amdgcn_raw_buffer_load_b32(rsrc, a, 0, 0); };
+    for (;;) {
+        const uint32_t v = page_table[(size_t)tile * kScoutTable + table_slot(x % kScoutTile)];
+        if ((v & kScoutEsc) == 0u) return tile * kScoutTile + v;
+        const RunInfo run = decode_run(rd, tile * kScoutTile + (v & 0x7fffu), end, pg.num_bits, 0xffffffffu);
+        if (run.kind >= kEnd) return kScoutNone;
+        if (run.next / kScoutTile != tile) return run.next;
+        x = run.next;  // behind the header it came from: the loop ends
+    }
+}
+
+// One workgroup per page.  Dynamic LDS: five arrays of kScoutLdsTiles + 8 words; pages with more tiles use
+// `scratch` (five arrays of n_tiles + 8 words from word 5 * (tile_base + 8 * page) on).
+__global__ __launch_bounds__(256) void scout_resolve_kernel(const PageDev *__restrict__ pages,
+                                                            const ScoutPage *__restrict__ sp, uint32_t n_pages,
+                                                            const uint16_t *__restrict__ table,
+                                                            uint32_t *__restrict__ tiles, uint32_t n_stiles,
+                                                            uint32_t *__restrict__ scratch) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_words[];
+    __shared__ uint32_t changed;
+    const uint32_t page = blockIdx.x;
+    if (page >= n_pages) return;
+    const ScoutPage s = sp[page];
+    const uint32_t n = s.n_tiles;
+    if (n == 0u) return;
+    const PageDev pg = pages[page];
+    const ScoutTiles t = scout_tiles(tiles, n_stiles);
+    const uint32_t delta = (uint32_t)(pg.in_addr & 15u);
+    const uint32_t end = delta + pg.in_len;
+    const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(pg.in_addr - delta, (end + 3u) & ~3u);
+    const uint16_t *const page_table = table + (size_t)s.tile_base * kScoutTable;
+
+    const uint32_t stride = (n <= kScoutLdsTiles ? kScoutLdsTiles : n) + 8u;
+    uint32_t *const arrays = n <= kScoutLdsTiles ? lds_words : scratch + 5 * ((size_t)s.tile_base + 8u * page);
+    uint32_t *const cand = arrays;                 // where tile k is entered, as far as is known
+    uint32_t *const leave = arrays + stride;       // where the chain from cand[k] leaves tile k
+    uint32_t *const flag = arrays + 2 * stride;    // bit 0: leave[k] is out of date; bit 1: tile k is reached
+    uint32_t *jump[2] = {arrays + 3 * stride, arrays + 4 * stride};  // the tile 2^r hops behind tile k (n: none)
+    const uint32_t tid = threadIdx.x;
+    auto tile_of = [&](uint32_t x) { return x == kScoutNone ? n : min(x / kScoutTile, n); };
+
+    for (uint32_t k = tid; k < n; k += 256u) {
+        cand[k] = k == 0u ? delta : k * kScoutTile;
+        flag[k] = 1u;
+    }
+    uint32_t rounds = 0;
+    while ((1u << rounds) < n) ++rounds;
+    for (uint32_t iter = 0; iter <= n; ++iter) {
+        __syncthreads();
+        if (tid == 0) changed = 0u;
+        for (uint32_t k = tid; k < n; k += 256u) {
+            if (flag[k] & 1u) leave[k] = scout_leave(pg, rsrc, end, page_table, cand[k]);
+            flag[k] = k == 0u ? 2u : 0u;
+            jump[0][k] = tile_of(leave[k]);
+        }
+        if (tid == 0) jump[0][n] = n, flag[n] = 0u;
+        __syncthreads();
+        // the tiles on the chain from tile 0: after round r those within 2^(r + 1) - 1 hops are marked
+        for (uint32_t r = 0; r <= rounds; ++r) {
+            const uint32_t *const from = jump[r & 1u];
+            uint32_t *const to = jump[(r & 1u) ^ 1u];
+            for (uint32_t k = tid; k <= n; k += 256u) {
+                const uint32_t j = from[k];
+                if (flag[k] & 2u) flag[j] = 2u;  // (tile n stands for "nowhere")
+                to[k] = from[j];
+            }
+            __syncthreads();
+        }
+        // every reached tile hands its exit to the tile it lands in
+        for (uint32_t k = tid; k < n; k += 256u) {
+            if ((flag[k] & 2u) == 0u) continue;
+            const uint32_t x = leave[k];
+            const uint32_t m = tile_of(x);
+            if (m < n && cand[m] != x) {
+                cand[m] = x;
+                flag[m] |= 1u;
+                changed = 1u;
+            }
+        }
+        __syncthreads();
+        if (changed == 0u) break;
+    }
+    for (uint32_t k = tid; k < n; k += 256u) {
+        const bool reached = (flag[k] & 2u) != 0u;
+        t.entry[s.tile_base + k] = reached ? cand[k] : kScoutNone;
+        t.exit[s.tile_base + k] = leave[k];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// count
+// ---------------------------------------------------------------------------
+// One wave per tile, four tiles per workgroup: the walk of parse_page (pq2_kernels.hip) from the tile's entry to
+// the first header behind the tile.
+template <bool kWide>
+__global__ __launch_bounds__(256) void scout_count_kernel(const PageDev *__restrict__ pages,
+                                                          const ScoutPage *__restrict__ sp, uint32_t *__restrict__ tiles,
+                                                          uint16_t *__restrict__ table, uint32_t n_stiles) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[4][kScoutWin];
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t g = blockIdx.x * 4u + wave;
+    if (g >= n_stiles) return;
+    const ScoutTiles tl = scout_tiles(tiles, n_stiles);
+    uint32_t pos = __builtin_amdgcn_readfirstlane(tl.entry[g]);
+    if (pos == kScoutNone) {
+        if (lane == 0) tl.vals[g] = 0u, tl.runs[g] = 0u;
+        return;
+    }
+    const uint32_t page = __builtin_amdgcn_readfirstlane(tl.page[g]);
+    const PageDev pg = pages[page];
+    const uint32_t t0 = (g - __builtin_amdgcn_readfirstlane(sp[page].tile_base)) * kScoutTile;
+    const uint32_t tile_end = t0 + kScoutTile;
+    const uint32_t delta = (uint32_t)(pg.in_addr & 15u);
+    const uint32_t end = delta + pg.in_len;
+    const uint32_t w = pg.num_bits;
+    const uint32_t rb = ceil8(w);
+    const uint32_t rb_mask = rb < 4 ? (1u << (rb * 8u)) - 1u : ~0u;
+    const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(pg.in_addr - delta, (end + 3u) & ~3u);
+    uint8_t *const win = lds[wave];
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)win;
+    static_assert(kScoutWin == 2u * 1024u + 64u, "the window is loaded in two rounds and four pieces");
+    {
+        const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rsrc, t0 + lane * 16u, 0, 0);
+        const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rsrc, t0 + 1024u + lane * 16u, 0, 0);
+        u32x4 c = {0u, 0u, 0u, 0u};
+        if (lane < 4u) c = __builtin_amdgcn_raw_buffer_load_b128(rsrc, t0 + 2048u + lane * 16u, 0, 0);
+        *(u32x4 *)&win[lane * 16u] = a;
+        *(u32x4 *)&win[1024u + lane * 16u] = b;
+        if (lane < 4u) *(u32x4 *)&win[2048u + lane * 16u] = c;
+        wave_sync();
+    }
+    auto rd = [&](uint32_t a) -> uint32_t { return __builtin_amdgcn_readfirstlane(*(const uint32_t *)&win[a - t0]); };
+    uint16_t *const list = table + (size_t)g * kScoutTable;  // the tile's table is not needed any more
+
+    uint32_t vals = 0, listed = 0, term = 0;
+    while (pos < tile_end && term == 0u) {
+        // ---- chase: park up to 64 runs, record i in lane i (see PQ2_CHASE) ---------------------------------
+        uint32_t r_pos = 0, r_lo = 0, r_hi = 0, r_info = 0;
+        uint32_t m = 0;
+        for (;;) {
+            uint32_t lo, hi, groups, t, bytes, nm1, chk, addr;
+            uint64_t exec_all;
+            uint32_t m0_kept;
+            const uint32_t voff = lds_base - t0;
+            // goes on while the next header lies inside the tile and inside the stream
+            const uint32_t chase_limit = min(end - 1u, tile_end - 2u);
+            if constexpr (kWide) {
+                PQ2_CHASE("v_readfirstlane_b32 %[hi], v3\n\t", "v_writelane_b32 %[r_hi], %[hi], m0\n\t")
+            } else {
+                PQ2_CHASE("", "")
+            }
+            if ((~lo & kExplicit) == 0u || nm1 > end - 1u) {
+                // three or more header bytes, a run cut by the end of the stream, or the end itself: the record
+                // parked last does not count
+                --m;
+                pos = __builtin_amdgcn_readlane(r_pos, m);
+                const RunInfo run = decode_run(rd, pos, end, w, 0xffffffffu);
+                const uint32_t e_lo = kExplicit | (run.kind << 16) | (((run.next - pos) & 0xffu) << 20);
+                const uint32_t e_hi = __builtin_amdgcn_readfirstlane(run.count);
+                const uint32_t e_info = __builtin_amdgcn_readfirstlane(run.kind == kRle ? run.value : run.payload);
+                uint32_t m0_was;
+                asm volatile(
+                    "s_mov_b32 %[m0_was], m0\n\t"
+                    "s_mov_b32 m0, %[m]\n\t"
+                    "v_writelane_b32 %[r_pos], %[pos], m0\n\t"
+                    "v_writelane_b32 %[r_lo], %[e_lo], m0\n\t"
+                    "v_writelane_b32 %[r_hi], %[e_hi], m0\n\t"
+                    "v_writelane_b32 %[r_info], %[e_info], m0\n\t"
+                    "s_mov_b32 m0, %[m0_was]"
+                    : [r_pos] "+v"(r_pos), [r_lo] "+v"(r_lo), [r_hi] "+v"(r_hi), [r_info] "+v"(r_info),
+                      [m0_was] "=&s"(m0_was)
+                    : [m] "s"(m), [pos] "s"(pos), [e_lo] "s"(e_lo), [e_hi] "s"(e_hi), [e_info] "s"(e_info));
+                ++m;
+                if (run.kind >= kEnd) {
+                    term = run.kind;
+                    break;
+                }
+                pos = run.next;
+            }
+            if (m == 64u || pos >= tile_end) break;
+        }
+        // ---- lane i decodes record i: the values of the runs, and the runs that hold any ------------------
+        const ParkedRun parked = decode_parked(r_pos, r_lo, r_hi, r_info, rb, rb_mask);
+        const uint32_t cnt = (lane < m && parked.kind < kEnd) ? min(parked.count, kValueCap) : 0u;
+        const uint32_t sum = __builtin_amdgcn_readlane(wave_inclusive_sum_saturating(cnt, kValueCap), 63);
+        vals = min(vals + sum, kValueCap);
+        const uint64_t holds = __ballot(cnt != 0u);
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(holds >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)holds, 0u));
+        if (cnt != 0u) list[listed + rank] = (uint16_t)(r_pos - t0);
+        listed += (uint32_t)__popcll(holds);
+    }
+    if (lane == 0) {
+        // the walk has to leave the tile where the table said it would
+        const uint32_t said = tl.exit[g];
+        const bool agrees = term != 0u ? said == kScoutNone : said == pos;
+        tl.vals[g] = vals;
+        tl.runs[g] = listed | (term == kPanic ? kScoutPanic : 0u) | (term != 0u ? kScoutTerm : 0u) | (agrees ? 0u : kScoutBad);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// scan
+// ---------------------------------------------------------------------------
+// The Resume entry of block b of the page (one round: the tiles of a page are numbered from tile_base[0] on).
+__device__ __forceinline__ Resume *scout_resume_entry(const PageDev &pg, Resume *resume, uint32_t b) {
+    return resume + (size_t)pg.tile_number(b / kBlocksPerTile) * kBlocksPerTile + (b % kBlocksPerTile);
+}
+// Blocks [from, n_blocks) of the page lie behind the last value the stream holds: zeros (mod.rs:95); closes the
+// header list after `n_runs` entries and gives the page its status.  All lanes of one wave.
+__device__ __forceinline__ void scout_close_page(const PageDev &pg, const uint32_t page, Resume *resume, uint32_t *run_pos,
+                                                 int32_t *status, ParseState *state, const uint32_t produced,
+                                                 const uint32_t n_runs, const int32_t st, const uint32_t lane) {
+    const uint32_t n_blocks = (pg.num_values + kBlockValues - 1u) / kBlockValues;
+    Resume e;
+    e.run_index = n_runs;
+    e.rem_kind = kRemMask | (kRle << 31);
+    e.payload = 0;
+    e.skip = kEndPos;
+    for (uint32_t b = (produced + kBlockValues - 1u) / kBlockValues + lane; b < n_blocks; b += 64u)
+        *scout_resume_entry(pg, resume, b) = e;
+    if (lane == 0) {
+        run_pos[pg.run_base + n_runs] = kEndPos;
+        status[page] = st;
+        ParseState ps;
+        ps.pos = 0, ps.produced = produced, ps.n_runs = n_runs, ps.done = 1u;
+        state[page] = ps;
+    }
+}
+
+// One workgroup per page.
+__global__ __launch_bounds__(256) void scout_scan_kernel(const PageDev *__restrict__ pages,
+                                                         const ScoutPage *__restrict__ sp, uint32_t n_pages,
+                                                         uint32_t *__restrict__ tiles, uint32_t n_stiles,
+                                                         ScoutFin *__restrict__ fin, Resume *__restrict__ resume,
+                                                         uint32_t *__restrict__ tile_page, uint32_t *__restrict__ run_pos,
+                                                         int32_t *__restrict__ status, ParseState *__restrict__ state) {
+    __shared__ uint32_t wave_vals[4], wave_runs[4], first_full, last_reached, any_flags;
+    const uint32_t page = blockIdx.x;
+    if (page >= n_pages) return;
+    const PageDev pg = pages[page];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t n = pg.num_values;
+    if (n == 0u) {
+        if (tid == 0) status[page] = 0;
+        return;
+    }
+    // expand_kernel finds its page through tile_page[tile]
+    for (uint32_t k = tid; k < (n + kTileValues - 1u) / kTileValues; k += 256u) tile_page[pg.tile_number(k)] = page;
+    const ScoutPage s = sp[page];
+    if (s.n_tiles == 0u) {  // decoder.rs:31-37: nothing to iterate
+        if (wave == 0u) scout_close_page(pg, page, resume, run_pos, status, state, 0u, 0u, 0, lane);
+        return;
+    }
+    const ScoutTiles t = scout_tiles(tiles, n_stiles);
+    if (tid == 0) first_full = kScoutNone, last_reached = 0u, any_flags = 0u;
+    uint32_t carry_vals = 0, carry_runs = 0;
+    for (uint32_t k0 = 0; k0 < s.n_tiles; k0 += 256u) {
+        __syncthreads();
+        const uint32_t k = k0 + tid;
+        const bool in = k < s.n_tiles;
+        const uint32_t g = s.tile_base + k;
+        const uint32_t v = in ? t.vals[g] : 0u;
+        const uint32_t rf = in ? t.runs[g] : 0u;
+        const bool reached = in && t.entry[g] != kScoutNone;
+        const uint32_t r = rf & kScoutRunsMask;
+        const uint32_t iv = wave_inclusive_sum_saturating(v, kValueCap);
+        const uint32_t ir = wave_inclusive_sum(r);
+        if (lane == 63u) wave_vals[wave] = iv, wave_runs[wave] = ir;
+        __syncthreads();
+        uint32_t bv = carry_vals, br = carry_runs;
+        for (uint32_t i = 0; i < 4u; ++i) {
+            if (i < wave) bv = min(bv + wave_vals[i], kValueCap), br += wave_runs[i];
+        }
+        const uint32_t excl_v = min(bv + (uint32_t)__builtin_amdgcn_update_dpp(0u, iv, 0x138, 0xf, 0xf, false), kValueCap);  // wave_shr:1
+        const uint32_t incl_v = min(bv + iv, kValueCap);
+        if (in) {
+            t.base_vals[g] = excl_v;
+            t.base_runs[g] = br + ir - r;
+        }
+        if (reached) {
+            atomicMax(&last_reached, k);
+            if (incl_v >= n && excl_v < n) atomicMin(&first_full, k);
+            if (rf & (kScoutPanic | kScoutBad)) atomicOr(&any_flags, rf & (kScoutPanic | kScoutBad));
+        }
+        for (uint32_t i = 0; i < 4u; ++i) carry_vals = min(carry_vals + wave_vals[i], kValueCap), carry_runs += wave_runs[i];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        ScoutFin f;
+        f.tile = first_full != kScoutNone ? first_full : last_reached;
+        f.flags = any_flags;
+        fin[page] = f;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// place
+// ---------------------------------------------------------------------------
+// One wave per tile, four tiles per workgroup: the place step of parse_page over the runs the tile lists.
+__global__ __launch_bounds__(256) void scout_place_kernel(const PageDev *__restrict__ pages,
+                                                          const ScoutPage *__restrict__ sp, uint32_t *__restrict__ tiles,
+                                                          const uint16_t *__restrict__ table, uint32_t n_stiles,
+                                                          const ScoutFin *__restrict__ fin, Resume *__restrict__ resume,
+                                                          uint32_t *__restrict__ run_pos, int32_t *__restrict__ status,
+                                                          ParseState *__restrict__ state) {
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t g = blockIdx.x * 4u + wave;
+    if (g >= n_stiles) return;
+    const ScoutTiles t = scout_tiles(tiles, n_stiles);
+    if (__builtin_amdgcn_readfirstlane(t.entry[g]) == kScoutNone) return;
+    const uint32_t page = __builtin_amdgcn_readfirstlane(t.page[g]);
+    const PageDev pg = pages[page];
+    const uint32_t n = pg.num_values;
+    uint32_t produced = __builtin_amdgcn_readfirstlane(t.base_vals[g]);
+    if (n == 0u || produced >= n) return;  // the page's last value lies in an earlier tile
+    const uint32_t k = g - __builtin_amdgcn_readfirstlane(sp[page].tile_base);
+    const uint32_t t0 = k * kScoutTile;
+    const uint32_t listed = __builtin_amdgcn_readfirstlane(t.runs[g]) & kScoutRunsMask;
+    uint32_t n_runs = __builtin_amdgcn_readfirstlane(t.base_runs[g]);
+    const uint32_t delta = (uint32_t)(pg.in_addr & 15u);
+    const uint32_t end = delta + pg.in_len;
+    const uint32_t w = pg.num_bits;
+    const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(pg.in_addr - delta, (end + 3u) & ~3u);
+    auto rd = [&](uint32_t a) -> uint32_t { return __builtin_amdgcn_raw_buffer_load_b32(rsrc, a, 0, 0); };
+    const uint16_t *const list = table + (size_t)g * kScoutTable;
+    uint32_t *const hdrs = run_pos + pg.run_base;
+
+    for (uint32_t i0 = 0; i0 < listed && produced < n; i0 += 64u) {
+        const uint32_t m = min(64u, listed - i0);
+        uint32_t r_pos = 0, kind = kRle, count = 0, info = 0, after = 0;
+        if (lane < m) {
+            r_pos = t0 + list[i0 + lane];
+            const RunInfo run = decode_run(rd, r_pos, end, w, 0xffffffffu);  // kBitpacked or kRle: it was listed
+            kind = run.kind;
+            count = run.count;
+            info = run.kind == kRle ? run.value : run.payload;
+            after = run.next;
+        }
+        // from here on as parse_page places the 64 runs of a pass
+        const uint32_t left = n - produced;  // > 0
+        const uint32_t cnt = lane < m ? min(count, left) : 0u;
+        const uint32_t incl = wave_inclusive_sum_saturating(cnt, left);
+        const uint32_t before = __builtin_amdgcn_update_dpp(0u, incl, 0x138, 0xf, 0xf, false);  // wave_shr:1
+        const uint32_t eff = min(cnt, left - before);  // the page ends inside or before this run: mod.rs:76-78
+        const bool yields = eff > 0u;
+        const uint64_t ymask = __ballot(yields);
+        const uint32_t idx =
+            n_runs + __builtin_amdgcn_mbcnt_hi((uint32_t)(ymask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ymask, 0u));
+        if (yields) hdrs[idx] = r_pos;
+        const uint32_t first = produced + before;
+        const uint32_t b_first = (first + kBlockValues - 1u) / kBlockValues;
+        const uint32_t b_last = (first + eff - 1u) / kBlockValues;  // meaningful where `yields`
+        const uint32_t nb = (yields && b_last >= b_first) ? b_last - b_first + 1u : 0u;
+        auto write_entries = [&](uint32_t b_from, uint32_t b_step, uint32_t b_to, uint32_t run_index, uint32_t run_first,
+                                 uint32_t run_eff, uint32_t run_kind, uint32_t run_info, uint32_t run_after) {
+            for (uint32_t b = b_from; b <= b_to; b += b_step) {
+                const uint32_t skip = b * kBlockValues - run_first;
+                Resume e;
+                e.run_index = run_index;
+                e.rem_kind = (run_eff - skip) | (run_kind << 31);
+                e.payload = run_info;
+                e.skip = run_kind == kRle ? run_after : skip;
+                *scout_resume_entry(pg, resume, b) = e;
+            }
+        };
+        if (nb != 0u && nb <= 4u) write_entries(b_first, 1u, b_last, idx, first, eff, kind, info, after);
+        for (uint64_t big = __ballot(nb > 4u); big != 0; big &= big - 1) {  // long runs: the whole wave writes
+            const uint32_t l = (uint32_t)__builtin_ctzll(big);
+            write_entries(__builtin_amdgcn_readlane(b_first, l) + lane, 64u, __builtin_amdgcn_readlane(b_last, l),
+                          __builtin_amdgcn_readlane(idx, l), __builtin_amdgcn_readlane(first, l),
+                          __builtin_amdgcn_readlane(eff, l), __builtin_amdgcn_readlane(kind, l),
+                          __builtin_amdgcn_readlane(info, l), __builtin_amdgcn_readlane(after, l));
+        }
+        n_runs += (uint32_t)__popcll(ymask);
+        produced += __builtin_amdgcn_readlane(incl, 63);
+    }
+    const ScoutFin f = fin[page];
+    if (__builtin_amdgcn_readfirstlane(f.tile) != k) return;
+    // this tile holds the page's last value, or the end of its chain
+    const uint32_t flags = __builtin_amdgcn_readfirstlane(f.flags);
+    int32_t st = 0;
+    if (produced < n && (flags & kScoutPanic)) st = 5;  // PQ2_REFERENCE_WOULD_PANIC
+    if (flags & kScoutBad) st = 6;                      // PQ2_DEVICE_ERROR: table and walk disagree
+    scout_close_page(pg, page, resume, run_pos, status, state, min(produced, n), n_runs, st, lane);
+}
+
+}  // namespace pq2
+
+// ---- launcher (called from pq2_api.cpp) -------------------------------------------
+// Bytes of device memory the scout kernels need for a batch with `n_stiles` stream tiles in `n_pages` pages:
+// the tables, the per-tile words, the per-page closing records and the resolve step's arrays for large pages.
+extern "C" uint32_t pq2_scout_tile_bytes() { return pq2::kScoutTile; }
+extern "C" size_t pq2_scout_table_bytes(uint64_t n_stiles) { return (size_t)n_stiles * pq2::kScoutTable * 2u; }
+extern "C" size_t pq2_scout_words_bytes(uint64_t n_stiles, uint64_t n_pages) {
+    return (7u * (size_t)n_stiles + 2u * (size_t)n_pages + 5u * ((size_t)n_stiles + 8u * (size_t)n_pages) + 16u) * 4u;
+}
+
+// The header walk of a whole batch.  `spages`: n_pages ScoutPage records (device); `table`, `words`: scratch of
+// the sizes above.  Leaves resume / tile_page / run_pos / status / state as parse_kernel's single round does.
+extern "C" hipError_t pq2_launch_scout(const void *pages, const void *spages, uint32_t n_pages, uint32_t n_stiles,
+                                       void *table, void *words, void *resume, uint32_t *tile_page, uint32_t *run_pos,
+                                       int32_t *status, void *state, uint32_t max_bits, hipStream_t stream) {
+    using namespace pq2;
+    if (n_pages == 0) return hipSuccess;
+    const PageDev *pg = (const PageDev *)pages;
+    const ScoutPage *sp = (const ScoutPage *)spages;
+    uint32_t *tiles = (uint32_t *)words;
+    ScoutFin *fin = (ScoutFin *)(tiles + 7u * (size_t)n_stiles);
+    uint32_t *scratch = (uint32_t *)(fin + n_pages);
+    uint16_t *tbl = (uint16_t *)table;
+    const uint32_t tile_groups = (n_stiles + 3u) / 4u;
+    if (n_stiles != 0u) {
+        hipLaunchKernelGGL(scout_map_kernel, dim3(n_pages), dim3(256), 0, stream, sp, n_pages, tiles, n_stiles);
+        hipLaunchKernelGGL(scout_table_kernel, dim3(tile_groups), dim3(256), 0, stream, pg, sp, tiles, tbl, n_stiles);
+        hipLaunchKernelGGL(scout_resolve_kernel, dim3(n_pages), dim3(256), 5u * (kScoutLdsTiles + 8u) * 4u, stream, pg, sp,
+                           n_pages, tbl, tiles, n_stiles, scratch);
+        if (max_bits > 16u)
+            hipLaunchKernelGGL(scout_count_kernel<true>, dim3(tile_groups), dim3(256), 0, stream, pg, sp, tiles, tbl, n_stiles);
+        else
+            hipLaunchKernelGGL(scout_count_kernel<false>, dim3(tile_groups), dim3(256), 0, stream, pg, sp, tiles, tbl, n_stiles);
+    }
+    hipLaunchKernelGGL(scout_scan_kernel, dim3(n_pages), dim3(256), 0, stream, pg, sp, n_pages, tiles, n_stiles, fin,
+                       (Resume *)resume, tile_page, run_pos, status, (ParseState *)state);
+    if (n_stiles != 0u)
+        hipLaunchKernelGGL(scout_place_kernel, dim3(tile_groups), dim3(256), 0, stream, pg, sp, tiles, tbl, n_stiles, fin,
+                           (Resume *)resume, run_pos, status, (ParseState *)state);
+    return hipGetLastError();
+}

@@ -26,13 +26,13 @@ from parquet2_amd.read.levels import get_bit_width
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["per_page", "ring"])
+@pytest.fixture(scope="module", params=["per_page", "ring", "scout"])
 def ctx(request):
     import os
 
     from parquet2_amd import Context
 
-    os.environ["PQ2_MODE"] = {"per_page": "page", "ring": "ring"}[request.param]
+    os.environ["PQ2_MODE"] = {"per_page": "page", "ring": "ring", "scout": "scout"}[request.param]
     try:
         c = Context(0)
     finally:

@@ -9,21 +9,22 @@ from parquet2_amd._lib import INVALID_PARAMETER, OK, REFERENCE_WOULD_PANIC
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["one_round", "four_rounds", "per_page", "ring"])
+@pytest.fixture(scope="module", params=["one_round", "four_rounds", "per_page", "ring", "scout"])
 def ctx(request):
-    """Every test runs four times, once per way a batch can be scheduled: parse_kernel + expand_kernel in one
-    round (what small batches of few pages get), the same with the round pipeline forced on (parse of part r + 1
-    on one stream while part r is expanded on another; large batches of few pages), decode_kernel, one
-    workgroup per page with the hand-off through device memory, and ring_kernel, one workgroup per page with
-    the stream staged once through an LDS ring (batches of many pages).  The context reads the knobs when it is
-    created."""
+    """Every test runs five times, once per way a batch can be scheduled: parse_kernel + expand_kernel in one
+    round, the same with the round pipeline forced on (parse of part r + 1 on one stream while part r is expanded
+    on another), decode_kernel, one workgroup per page with the hand-off through device memory, ring_kernel, one
+    workgroup per page with the stream staged once through an LDS ring (batches of many pages), and the scout
+    kernels, which walk the headers of all pages in parallel over tiles of the streams, in front of expand_kernel
+    (batches of few pages).  The context reads the knobs when it is created."""
     import os
 
     from parquet2_amd import Context
 
     knobs = {"one_round": {"PQ2_MODE": "tile"},
              "four_rounds": {"PQ2_MODE": "tile", "PQ2_MIN_ROUNDED_TILES": "1", "PQ2_ROUND_SPLIT": "0.1,0.3,0.6"},
-             "per_page": {"PQ2_MODE": "page"}, "ring": {"PQ2_MODE": "ring"}}[request.param]
+             "per_page": {"PQ2_MODE": "page"}, "ring": {"PQ2_MODE": "ring"},
+             "scout": {"PQ2_MODE": "scout"}}[request.param]
     os.environ.update(knobs)
     try:
         c = Context(0)

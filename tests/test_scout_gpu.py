@@ -1,0 +1,240 @@
+"""The scout kernels (the header walk spread over tiles of the streams) against the CPU oracle, on the inputs that
+are hard for them: pages that are nothing but headers, runs that pass over many tiles, headers the table leaves
+to the exact decoder, chains that never fall into step, pages too large for the in-LDS resolve step.  The
+adversarial batch of BASELINE configs[3] (16 pages x 2^20 values at widths 3 / 17 / 31) runs in every schedule."""
+import os
+
+import numpy as np
+import pytest
+
+from parquet2_amd import synth
+from parquet2_amd._lib import OK, REFERENCE_WOULD_PANIC
+
+pytestmark = pytest.mark.gpu
+
+TILE = 2048  # stream bytes per tile of the scout kernels
+
+
+def _context(mode):
+    from parquet2_amd import Context
+
+    os.environ["PQ2_MODE"] = mode
+    try:
+        return Context(0)
+    finally:
+        del os.environ["PQ2_MODE"]
+
+
+@pytest.fixture(scope="module")
+def scout():
+    c = _context("scout")
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module", params=["tile", "page", "ring", "scout"])
+def any_schedule(request):
+    c = _context(request.param)
+    yield c
+    c.close()
+
+
+def varint(v):
+    out = bytearray()
+    while True:
+        b = v & 0x7F
+        v >>= 7
+        if v:
+            out.append(b | 0x80)
+        else:
+            out.append(b)
+            return bytes(out)
+
+
+def rle_run(count, value, w):
+    return varint(count << 1) + int(value).to_bytes((w + 7) // 8, "little")
+
+
+def packed_run(groups, w, rng):
+    return varint((groups << 1) | 1) + rng.integers(0, 256, groups * w, dtype=np.uint8).tobytes()
+
+
+def check_batch(ctx, oracle, pages, align=16, msg=""):
+    """pages: (stream, w, n); decodes them as one batch and compares statuses and values with the oracle."""
+    batch = synth.PageBatch(align=align)
+    for k, (stream, w, n) in enumerate(pages):
+        if align == 1:  # every stream at another address modulo 16
+            pad = 1 + k % 5
+            batch.chunks.append(np.full(pad, 0x02, np.uint8))
+            batch.in_bytes += pad
+        batch.add(stream, w, n, out_align=1 if align == 1 else 4)
+    data, descs, out_values = batch.finish()
+    got, status = ctx.decode_batch_host(data, descs, out_values)
+    for k, (stream, w, n) in enumerate(pages):
+        st_o, exp = oracle.hybrid_rle_decode(stream, w, n)
+        assert status[k] == st_o, (msg, k, status[k], st_o)
+        if st_o == OK:
+            o = int(descs[k]["out_off"])
+            bad = np.nonzero(got[o:o + n] != exp)[0]
+            assert bad.size == 0, (msg, "page", k, "first mismatch at", bad[:5], got[o:o + n][bad[:5]], exp[bad[:5]])
+    return status
+
+
+@pytest.mark.parametrize("w", [3, 17, 31])
+def test_adversarial_batch_every_schedule(any_schedule, oracle, w):
+    """BASELINE configs[3] at full size: 16 distinct pages of 2^20 values, alternating 1-8-value RLE runs and
+    one-group bit-packed runs."""
+    import torch
+
+    n = 1 << 20
+    batch = synth.PageBatch()
+    pages = []
+    for p in range(16):
+        stream, expected = synth.adversarial(synth.seed_for(4, 16 * w + p), n, w)
+        batch.add(stream, w, n)
+        pages.append((stream, expected))
+    data, descs, out_values = batch.finish()
+    d_in = torch.from_numpy(data).cuda()
+    d_out = torch.full((out_values,), -1, dtype=torch.int32, device="cuda")
+    st = any_schedule.decode_batch_device(d_in.data_ptr(), d_in.numel(), descs, d_out.data_ptr(), out_values,
+                                          torch.cuda.current_stream().cuda_stream)
+    assert (st == OK).all()
+    got = d_out.cpu().numpy().view(np.uint32)
+    for p, (stream, expected) in enumerate(pages):
+        o = int(descs[p]["out_off"])
+        assert (got[o:o + n] == expected).all(), p
+    for p in (0, 7, 15):
+        st_o, exp = oracle.hybrid_rle_decode(pages[p][0], w, n)
+        assert st_o == OK and (exp == pages[p][1]).all()
+
+
+def test_runs_that_pass_over_tiles(scout, oracle):
+    """Bit-packed runs of up to 40 000 groups (headers of three bytes, payloads that span hundreds of tiles)
+    between short runs, RLE runs of up to 2^22 values (headers of up to four bytes), at several widths."""
+    rng = np.random.default_rng(11)
+    pages = []
+    for w in (1, 5, 12, 20, 32):
+        parts, total = [], 0
+        for i in range(60):
+            kind = int(rng.integers(0, 5))
+            if kind == 0:
+                g = int(rng.integers(8192, 40000))
+                parts.append(packed_run(g, w, rng))
+                total += 8 * g
+            elif kind == 1:
+                c = int(rng.integers(8192, 1 << 22))
+                parts.append(rle_run(c, rng.integers(0, 1 << min(w, 31)), w))
+                total += c
+            elif kind == 2:
+                g = int(rng.integers(0, 64))
+                parts.append(packed_run(g, w, rng))
+                total += 8 * g
+            else:
+                c = int(rng.integers(0, 200))
+                parts.append(rle_run(c, rng.integers(0, 1 << min(w, 31)), w))
+                total += c
+        stream = np.frombuffer(b"".join(parts), dtype=np.uint8)
+        pages.append((stream, w, total))
+        pages.append((stream, w, total // 3))        # the page ends inside the stream
+        pages.append((stream, w, total + 5000))      # ... and behind it: zeros
+        pages.append((stream[:len(stream) // 2], w, total))  # a stream cut somewhere: clamp, panic or zeros
+    status = check_batch(scout, oracle, pages, align=1)
+    assert OK in status.tolist()
+
+
+def test_pages_beyond_the_resolve_step_in_lds(scout, oracle):
+    """More than 2048 stream tiles in one page: the resolve step keeps its arrays in device memory."""
+    from parquet2_amd.encoding.hybrid_rle import encode_u32
+
+    n = 1_500_000
+    vals = synth.uniform_values(77, n, 32)
+    one_run = np.frombuffer(bytes(encode_u32(vals, 32)), dtype=np.uint8)  # 6 MB: one bit-packed run
+    assert one_run.size > 2048 * TILE
+    stream, expected = synth.adversarial(12345, 3_000_000, 17)  # about 5 MB of headers
+    assert stream.size > 2048 * TILE
+    dict_stream, dict_vals = synth.dict_page(99, 4_000_000, 12)
+    assert dict_stream.size > 2048 * TILE
+    pages = [(one_run, 32, n), (stream, 17, 3_000_000), (dict_stream, 12, 4_000_000), (stream, 17, 1000)]
+    check_batch(scout, oracle, pages)
+    got, st = scout.decode_page_host(one_run, 32, n)
+    assert st == OK and (got == vals).all()
+
+
+def test_chains_that_never_fall_into_step(scout, oracle):
+    """Width 8, every run an RLE run of one value whose value byte reads as an RLE header itself: the chain from
+    an even offset and the chain from an odd one never meet.  With the stream at an odd address every tile's first
+    guess is on the wrong chain, and the resolve step gets one more tile right per round."""
+    rng = np.random.default_rng(3)
+    runs = 40_000
+    values = (rng.integers(1, 60, runs) * 2).astype(np.uint8)
+    stream = np.empty(2 * runs, np.uint8)
+    stream[0::2] = 0x02
+    stream[1::2] = values
+    for pad in (1, 2):
+        batch = synth.PageBatch(align=1)
+        batch.chunks.append(np.full(pad, 0x02, np.uint8))
+        batch.in_bytes += pad
+        batch.add(stream, 8, runs)
+        data, descs, out_values = batch.finish()
+        got, status = scout.decode_batch_host(data, descs, out_values)
+        assert status[0] == OK and (got == values).all(), pad
+    st_o, exp = oracle.hybrid_rle_decode(stream, 8, runs)
+    assert st_o == OK and (exp == values).all()
+
+
+def test_headers_left_to_the_exact_decoder(scout, oracle):
+    """Every kind of header the table does not follow itself, in the middle of tiles, at their edges and at the end
+    of streams: varints of 3 to 10 bytes, runs cut by the end of the stream, a header in the last byte, value bytes
+    that are missing, the tenth varint byte above 1."""
+    rng = np.random.default_rng(5)
+    pages = []
+    for w in (1, 8, 9, 24):
+        body = b"".join(rle_run(int(rng.integers(1, 9)), rng.integers(0, 1 << w), w) if i % 2 else packed_run(1, w, rng)
+                        for i in range(3000))
+        long_varint = bytes([0x90, 0x80, 0x80, 0x00]) + int(7).to_bytes((w + 7) // 8, "little")  # RLE, 8 values, 4 bytes
+        tails = [
+            varint(16),                                   # an RLE header in the last byte: dropped
+            varint(16) + b"\x01" * ((w + 7) // 8 - 1),    # value bytes missing (w > 8): the reference panics
+            varint((500 << 1) | 1) + b"\xff" * (3 * w),   # a bit-packed run cut by the end: clamped
+            bytes([0x80, 0x80]),                          # a varint cut by the end
+            bytes([0x80] * 9 + [0x02, 1, 1, 1, 1]),       # tenth varint byte above 1: the reference panics
+            bytes([0x80] * 9 + [0x01, 7, 0, 0, 0]),       # a ten-byte header of an RLE run of 2^62 values
+            b"",
+        ]
+        for cut in (0, 1, TILE - 3, TILE - 1, TILE, 3 * TILE + 5):
+            front = body[:cut] if cut else b""
+            # keep whole runs only, so that what follows starts at a header
+            whole, pos = bytearray(), 0
+            while pos < len(front):
+                ind = front[pos]
+                step = 1 + (w if ind & 1 else (w + 7) // 8)
+                if pos + step > len(front):
+                    break
+                whole += front[pos:pos + step]
+                pos += step
+            for tail in tails:
+                stream = bytes(whole) + long_varint + tail
+                pages.append((np.frombuffer(stream, dtype=np.uint8), w, 30_000))
+    status = check_batch(scout, oracle, pages, align=1)
+    assert {OK, REFERENCE_WOULD_PANIC} <= set(status.tolist())
+
+
+def test_pages_without_a_walk_among_others(scout, oracle):
+    """Width 0, empty streams and pages of no values (no stream tiles) beside ordinary pages, 200 pages in all."""
+    rng = np.random.default_rng(8)
+    pages = []
+    for k in range(200):
+        kind = k % 5
+        if kind == 0:
+            pages.append((np.zeros(0, np.uint8), int(rng.integers(1, 33)), int(rng.integers(0, 9000))))
+        elif kind == 1:
+            pages.append((rng.integers(0, 256, 40, dtype=np.uint8), 0, int(rng.integers(1, 9000))))
+        elif kind == 2:
+            stream, _ = synth.dict_page(k, 5000, 9)
+            pages.append((stream, 9, 0))
+        else:
+            w = int(rng.integers(1, 33))
+            n = int(rng.integers(1, 60_000))
+            stream, _ = synth.dict_page(k, n, w, 10.0, 20.0)
+            pages.append((stream, w, n + (k % 3) * 100))
+    check_batch(scout, oracle, pages, align=1)

@@ -416,7 +416,9 @@ def main():
     elapsed = time.perf_counter() - t0
     parse_ms, expand_ms, batches, expand_launches = ctx.kernel_times()
     ctx.enable_profiling(False)
-    kernel_name = ctx.last_schedule()
+    schedule = ctx.last_schedule()
+    kernel_name = schedule.split("+")[-1]  # the kernel that writes the values ("scout+expand_kernel": the scout
+    #                                        kernels walk the headers in front of it; their time is parse_kernel_ms)
 
     if distributed:
         rdev = dev if backend == "nccl" else torch.device("cpu")
@@ -463,7 +465,7 @@ def main():
                 "sharding": "pages partitioned across ranks, no collective",
             },
             "roofline": {
-                "bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "bound": "hbm", "kernel": kernel_name, "schedule": schedule, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": int(bytes_per_launch),

@@ -124,6 +124,7 @@ __global__ __launch_bounds__(256) void scout_table_kernel(const PageDev *__restr
                                                           const ScoutPage *__restrict__ sp, uint32_t *__restrict__ tiles,
                                                           uint16_t *__restrict__ table, uint32_t n_stiles) {
     __shared__ __attribute__((aligned(16))) uint16_t lds[4][kScoutTable];
+    __shared__ uint32_t votes[4][kScoutTile / 2u];  // two 16-bit counters per word
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t g = blockIdx.x * 4u + wave;
@@ -144,6 +145,31 @@ __global__ __launch_bounds__(256) void scout_table_kernel(const PageDev *__restr
             if (v < kScoutTile) tbl[at] = tbl[table_slot(v)];
         }
         wave_sync();
+    }
+    // A guess at where the page's chain enters the next tile: the offset there at which most of this tile's chains
+    // arrive.  Every header of the page's chain inside this tile is an offset that votes for the true one, while
+    // the chains that start inside bit-packed payloads scatter.  (Only a guess: the resolve step decides.)
+    {
+        uint32_t *const vote = votes[wave];
+#pragma unroll
+        for (uint32_t i = 0; i < kScoutTile / 2u / 64u; ++i) vote[i * 64u + lane] = 0u;
+        wave_sync();
+#pragma unroll 4
+        for (uint32_t i = 0; i < kScoutSeg; ++i) {
+            const uint32_t v = tbl[i * kScoutRow + lane];
+            if (v >= kScoutTile && v < 2u * kScoutTile) atomicAdd(&vote[(v - kScoutTile) >> 1], 1u << ((v & 1u) * 16u));
+        }
+        wave_sync();
+        uint32_t best = 0;  // votes << 11 | offset in the next tile
+#pragma unroll
+        for (uint32_t i = 0; i < kScoutTile / 2u / 64u; ++i) {
+            const uint32_t at = lane * (kScoutTile / 2u / 64u) + i;
+            const uint32_t word = vote[at];
+            best = max(best, ((word & 0xffffu) << 11) | (2u * at));
+            best = max(best, ((word >> 16) << 11) | (2u * at + 1u));
+        }
+        best = __builtin_amdgcn_readlane(wave_inclusive_max(best), 63);
+        if (lane == 0) t.exit[g] = (best >> 11) >= 2u ? t0 + kScoutTile + (best & (kScoutTile - 1u)) : kScoutNone;
     }
     // the table as it lies in LDS: kScoutTable * 2 = 4224 bytes = 264 pieces of 16
     u32x4 *const dst = (u32x4 *)(table + (size_t)g * kScoutTable);
@@ -174,8 +200,8 @@ __device__ __forceinline__ uint32_t scout_leave(const PageDev &pg, const __amdgp
     }
 }
 
-// One workgroup per page.  Dynamic LDS: five arrays of kScoutLdsTiles + 8 words; pages with more tiles use
-// `scratch` (five arrays of n_tiles + 8 words from word 5 * (tile_base + 8 * page) on).
+// One workgroup per page.  Dynamic LDS: six arrays of kScoutLdsTiles + 8 words; pages with more tiles use
+// `scratch` (six arrays of n_tiles + 8 words from word 6 * (tile_base + 8 * page) on).
 __global__ __launch_bounds__(256) void scout_resolve_kernel(const PageDev *__restrict__ pages,
                                                             const ScoutPage *__restrict__ sp, uint32_t n_pages,
                                                             const uint16_t *__restrict__ table,
@@ -196,16 +222,24 @@ __global__ __launch_bounds__(256) void scout_resolve_kernel(const PageDev *__res
     const uint16_t *const page_table = table + (size_t)s.tile_base * kScoutTable;
 
     const uint32_t stride = (n <= kScoutLdsTiles ? kScoutLdsTiles : n) + 8u;
-    uint32_t *const arrays = n <= kScoutLdsTiles ? lds_words : scratch + 5 * ((size_t)s.tile_base + 8u * page);
+    uint32_t *const arrays = n <= kScoutLdsTiles ? lds_words : scratch + 6 * ((size_t)s.tile_base + 8u * page);
     uint32_t *const cand = arrays;                 // where tile k is entered, as far as is known
     uint32_t *const leave = arrays + stride;       // where the chain from cand[k] leaves tile k
     uint32_t *const flag = arrays + 2 * stride;    // bit 0: leave[k] is out of date; bit 1: tile k is reached
     uint32_t *jump[2] = {arrays + 3 * stride, arrays + 4 * stride};  // the tile 2^r hops behind tile k (n: none)
+    uint32_t *const offer = arrays + 5 * stride;   // who hands tile k its entry: reached << 31 | (tile + 1)
     const uint32_t tid = threadIdx.x;
     auto tile_of = [&](uint32_t x) { return x == kScoutNone ? n : min(x / kScoutTile, n); };
 
+    // first guesses: the page's first byte; elsewhere what the table step saw most chains of the tile before arrive
+    // at, or the tile's first byte
     for (uint32_t k = tid; k < n; k += 256u) {
-        cand[k] = k == 0u ? delta : k * kScoutTile;
+        uint32_t x = k == 0u ? delta : k * kScoutTile;
+        if (k != 0u) {
+            const uint32_t hint = t.exit[s.tile_base + k - 1u];
+            if (hint != kScoutNone && hint / kScoutTile == k) x = hint;
+        }
+        cand[k] = x;
         flag[k] = 1u;
     }
     uint32_t rounds = 0;
@@ -217,6 +251,7 @@ __global__ __launch_bounds__(256) void scout_resolve_kernel(const PageDev *__res
             if (flag[k] & 1u) leave[k] = scout_leave(pg, rsrc, end, page_table, cand[k]);
             flag[k] = k == 0u ? 2u : 0u;
             jump[0][k] = tile_of(leave[k]);
+            offer[k] = 0u;
         }
         if (tid == 0) jump[0][n] = n, flag[n] = 0u;
         __syncthreads();
@@ -231,19 +266,26 @@ __global__ __launch_bounds__(256) void scout_resolve_kernel(const PageDev *__res
             }
             __syncthreads();
         }
-        // every reached tile hands its exit to the tile it lands in
+        // Every tile hands its exit to the tile it lands in.  A reached tile's offer counts before any other (the
+        // reached tiles are one chain, so at most one of them lands in a tile); among the others, which only
+        // speed things up where their own guess is right, the nearest one.
         for (uint32_t k = tid; k < n; k += 256u) {
-            if ((flag[k] & 2u) == 0u) continue;
-            const uint32_t x = leave[k];
-            const uint32_t m = tile_of(x);
-            if (m < n && cand[m] != x) {
+            const uint32_t m = tile_of(leave[k]);
+            if (m < n) atomicMax(&offer[m], ((flag[k] & 2u) << 30) | (k + 1u));
+        }
+        __syncthreads();
+        for (uint32_t m = tid; m < n; m += 256u) {
+            const uint32_t o = offer[m];
+            if (o == 0u) continue;
+            const uint32_t x = leave[(o & 0x7fffffffu) - 1u];
+            if (cand[m] != x) {
                 cand[m] = x;
                 flag[m] |= 1u;
-                changed = 1u;
+                if (o >> 31) changed = 1u;
             }
         }
         __syncthreads();
-        if (changed == 0u) break;
+        if (changed == 0u) break;  // every reached tile is entered where its predecessor leaves
     }
     for (uint32_t k = tid; k < n; k += 256u) {
         const bool reached = (flag[k] & 2u) != 0u;
@@ -559,7 +601,7 @@ __global__ __launch_bounds__(256) void scout_place_kernel(const PageDev *__restr
 extern "C" uint32_t pq2_scout_tile_bytes() { return pq2::kScoutTile; }
 extern "C" size_t pq2_scout_table_bytes(uint64_t n_stiles) { return (size_t)n_stiles * pq2::kScoutTable * 2u; }
 extern "C" size_t pq2_scout_words_bytes(uint64_t n_stiles, uint64_t n_pages) {
-    return (7u * (size_t)n_stiles + 2u * (size_t)n_pages + 5u * ((size_t)n_stiles + 8u * (size_t)n_pages) + 16u) * 4u;
+    return (7u * (size_t)n_stiles + 2u * (size_t)n_pages + 6u * ((size_t)n_stiles + 8u * (size_t)n_pages) + 16u) * 4u;
 }
 
 // The header walk of a whole batch.  `spages`: n_pages ScoutPage records (device); `table`, `words`: scratch of
@@ -579,7 +621,7 @@ extern "C" hipError_t pq2_launch_scout(const void *pages, const void *spages, ui
     if (n_stiles != 0u) {
         hipLaunchKernelGGL(scout_map_kernel, dim3(n_pages), dim3(256), 0, stream, sp, n_pages, tiles, n_stiles);
         hipLaunchKernelGGL(scout_table_kernel, dim3(tile_groups), dim3(256), 0, stream, pg, sp, tiles, tbl, n_stiles);
-        hipLaunchKernelGGL(scout_resolve_kernel, dim3(n_pages), dim3(256), 5u * (kScoutLdsTiles + 8u) * 4u, stream, pg, sp,
+        hipLaunchKernelGGL(scout_resolve_kernel, dim3(n_pages), dim3(256), 6u * (kScoutLdsTiles + 8u) * 4u, stream, pg, sp,
                            n_pages, tbl, tiles, n_stiles, scratch);
         if (max_bits > 16u)
             hipLaunchKernelGGL(scout_count_kernel<true>, dim3(tile_groups), dim3(256), 0, stream, pg, sp, tiles, tbl, n_stiles);

@@ -85,9 +85,15 @@ const char *pq2_last_error(const pq2_ctx *ctx);
 int32_t pq2_ctx_enable_profiling(pq2_ctx *ctx, int32_t on);
 /* Name of the kernel that produced the values of the last batch on this context ("ring_kernel": one
  * workgroup per page, the stream staged once through LDS; "decode_kernel": one workgroup per page, hand-off
- * through device memory; "expand_kernel": one wave per 4096 values behind parse_kernel; "" before the first
- * batch).  For benchmark reports. */
+ * through device memory; "expand_kernel": one wave per 4096 values behind parse_kernel;
+ * "scout+expand_kernel": the same behind the scout kernels, which walk the headers of all pages in parallel over
+ * tiles of the streams; "" before the first batch).  For benchmark reports. */
 const char *pq2_ctx_last_schedule(const pq2_ctx *ctx);
+/* Diagnostics of the scout kernels: for every page of the last batch on this context, the number of rounds its
+ * resolve step took until every tile of the page's stream was entered where the one before it is left (0 for a
+ * page without headers to walk).  Waits for the batch.  PQ2_INVALID_PARAMETER if the last batch was not decoded
+ * through the scout kernels or n_pages is not its page count.  No counterpart in the reference. */
+int32_t pq2_ctx_scout_rounds(pq2_ctx *ctx, uint32_t *rounds, uint64_t n_pages);
 int32_t pq2_ctx_kernel_times(pq2_ctx *ctx, double *parse_ms, double *expand_ms, uint64_t *batches,
                              uint64_t *expand_launches);
 

@@ -50,6 +50,7 @@ uint32_t pq2_ring_ticket_bytes();
 uint32_t pq2_scout_tile_bytes();  // pq2_scout.hip
 size_t pq2_scout_table_bytes(uint64_t n_stiles);
 size_t pq2_scout_words_bytes(uint64_t n_stiles, uint64_t n_pages);
+size_t pq2_scout_rounds_at(uint64_t n_stiles, uint64_t n_pages);
 hipError_t pq2_launch_scout(const void *pages, const void *spages, uint32_t n_pages, uint32_t n_stiles, void *table,
                             void *words, void *resume, uint32_t *tile_page, uint32_t *run_pos, int32_t *status, void *state,
                             uint32_t max_bits, hipStream_t stream);
@@ -62,7 +63,8 @@ constexpr uint32_t kBlocksPerTile = 4;
 constexpr uint32_t kRounds = 4;          // must match pq2::kRounds
 constexpr uint64_t kMinRoundedTiles = 16384;  // batches below 64 Mi values are decoded in one round
 constexpr size_t kParseStateBytes = 16;  // sizeof(pq2::ParseState)
-constexpr uint64_t kFusedMinPages = 64;  // batches of at least this many pages take one workgroup per page
+constexpr uint64_t kFusedMinPages = 64;  // batches of at least this many pages take one workgroup per page ...
+constexpr uint64_t kScoutMaxPages = 96;  // ... unless they have fewer than this many: then the scout kernels walk the headers
 
 struct ScoutPage {  // must match pq2::ScoutPage
     uint32_t tile_base, n_tiles;
@@ -150,6 +152,8 @@ struct pq2_ctx {
     DevBuf d_meta, d_status, d_resume, d_tile_page, d_run_pos, d_state;
     DevBuf d_tickets;  // decode_kernel's per-compute-unit counters (zeroed once; only their low bits matter)
     DevBuf d_scout_table, d_scout_words;  // the scout kernels' tables and per-tile words
+    uint64_t last_scout_tiles = 0;        // stream tiles of the last batch, if the scout kernels walked it
+    bool last_scout = false;
     // pq2_decode_dict_batch_device: the decoded indices, and the per-page gather descriptors (page-locked + device)
     DevBuf d_indices, d_gather;
     void *h_gather = nullptr;
@@ -286,6 +290,7 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
     // Until this batch is accepted and enqueued there is no batch whose statuses could be fetched: a call that
     // fails below leaves pq2_fetch_status nothing to report (n_pages = 0) instead of an earlier batch's array.
     ctx->last_n_pages = 0;
+    ctx->last_scout = false;
     ctx->host_status.assign(n_pages, PQ2_OK);
     if (n_pages == 0) {
         ctx->last_stream = stream;
@@ -344,7 +349,7 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
     // read; fewer pages: the tiles of all pages share the whole GPU
     // few pages: no page's walk has another page's expansion to hide behind, so the walk itself is spread over
     // the GPU (not where the streams' addresses are only known on the device)
-    const bool scout = !front && (ctx->mode == pq2_ctx::kScout || (ctx->mode == pq2_ctx::kAuto && n_pages < kFusedMinPages));
+    const bool scout = !front && (ctx->mode == pq2_ctx::kScout || (ctx->mode == pq2_ctx::kAuto && n_pages < kScoutMaxPages));
     const bool ring = !scout && (ctx->mode == pq2_ctx::kRing || (ctx->mode == pq2_ctx::kAuto && n_pages >= kFusedMinPages));
     const bool per_page = ring || ctx->mode == pq2_ctx::kPerPage;
     // tiles are numbered round-major: all tiles of round 0 of all pages, then round 1, ...
@@ -522,6 +527,8 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
     }
     if (ctx->profiling) ++ctx->stamped_batches;
     ctx->last_n_pages = n_pages;
+    ctx->last_scout = scout;
+    ctx->last_scout_tiles = stiles;
     ctx->last_schedule = ring ? "ring_kernel" : per_page ? "decode_kernel" : scout ? "scout+expand_kernel" : "expand_kernel";
     return PQ2_OK;
 }
@@ -623,6 +630,18 @@ const char *pq2_strerror(int32_t status) {
 const char *pq2_last_error(const pq2_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
 
 const char *pq2_ctx_last_schedule(const pq2_ctx *ctx) { return ctx ? ctx->last_schedule : ""; }
+
+int32_t pq2_ctx_scout_rounds(pq2_ctx *ctx, uint32_t *rounds, uint64_t n_pages) {
+    if (!ctx || (!rounds && n_pages)) return PQ2_INVALID_PARAMETER;
+    if (!ctx->last_scout || n_pages != ctx->last_n_pages)
+        return fail(ctx, PQ2_INVALID_PARAMETER, "the last batch did not go through the scout kernels with this many pages");
+    if (n_pages == 0) return PQ2_OK;
+    PQ2_HIP(ctx, hipSetDevice(ctx->device));
+    const uint8_t *at = static_cast<const uint8_t *>(ctx->d_scout_words.ptr) + pq2_scout_rounds_at(ctx->last_scout_tiles, n_pages);
+    PQ2_HIP(ctx, hipMemcpyAsync(rounds, at, n_pages * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->last_stream));
+    PQ2_HIP(ctx, hipStreamSynchronize(ctx->last_stream));
+    return PQ2_OK;
+}
 
 int32_t pq2_ctx_enable_profiling(pq2_ctx *ctx, int32_t on) {
     if (!ctx) return PQ2_INVALID_PARAMETER;

@@ -73,7 +73,8 @@ __device__ __forceinline__ void parse_page(const PageDev &pg, const uint32_t pag
                                            Resume *__restrict__ resume, uint32_t *__restrict__ tile_page,
                                            uint32_t *__restrict__ run_pos, int32_t *__restrict__ status,
                                            ParseState *__restrict__ state, const uint32_t round,
-                                           const uint32_t lane, Publish publish) {
+                                           const uint32_t lane, Publish publish, uint32_t passes = 0xffffffffu) {
+    // `passes`: the walk also stops after this many passes of up to 64 runs each (probe_kernel)
     const uint32_t n = pg.num_values;
     if (n == 0) {
         if (lane == 0 && round == 0) status[page] = 0;
@@ -312,6 +313,7 @@ __device__ __forceinline__ void parse_page(const PageDev &pg, const uint32_t pag
         }
         if (produced >= target) break;
         announce = produced;
+        if (--passes == 0u) break;
     }
     if (lane == 0) {
         ParseState out;
@@ -331,6 +333,21 @@ __global__ __launch_bounds__(64) void parse_kernel(const PageDev *__restrict__ p
     if (page >= n_pages) return;
     const PageDev pg = pages[page];
     parse_page<kWide>(pg, page, win, resume, tile_page, run_pos, status, state, round, threadIdx.x, [](uint32_t) {});
+}
+
+// The first `passes` passes of the walk of every page: a page of few runs (one bit-packed run, as the reference's
+// own encoder writes it: src/encoding/hybrid_rle/encoder.rs:59-70) is complete after them (ParseState::done), and
+// the scout kernels leave it alone.
+template <bool kWide>
+__global__ __launch_bounds__(64) void probe_kernel(const PageDev *__restrict__ pages, uint32_t n_pages,
+                                                   Resume *__restrict__ resume, uint32_t *__restrict__ tile_page,
+                                                   uint32_t *__restrict__ run_pos, int32_t *__restrict__ status,
+                                                   ParseState *__restrict__ state, uint32_t passes) {
+    __shared__ __attribute__((aligned(16))) uint8_t win[kWin];
+    const uint32_t page = blockIdx.x;
+    if (page >= n_pages) return;
+    const PageDev pg = pages[page];
+    parse_page<kWide>(pg, page, win, resume, tile_page, run_pos, status, state, 0u, threadIdx.x, [](uint32_t) {}, passes);
 }
 
 // ---------------------------------------------------------------------------
@@ -1805,6 +1822,19 @@ extern "C" hipError_t pq2_launch_parse(const void *pages, uint32_t n_pages, void
     else
         hipLaunchKernelGGL(pq2::parse_kernel<false>, dim3(n_pages), dim3(64), 0, stream, (const pq2::PageDev *)pages,
                            n_pages, (pq2::Resume *)resume, tile_page, run_pos, status, (pq2::ParseState *)state, round);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t pq2_launch_probe(const void *pages, uint32_t n_pages, void *resume, uint32_t *tile_page,
+                                       uint32_t *run_pos, int32_t *status, void *state, uint32_t passes, uint32_t max_bits,
+                                       hipStream_t stream) {
+    if (n_pages == 0) return hipSuccess;
+    if (max_bits > 16u)
+        hipLaunchKernelGGL(pq2::probe_kernel<true>, dim3(n_pages), dim3(64), 0, stream, (const pq2::PageDev *)pages,
+                           n_pages, (pq2::Resume *)resume, tile_page, run_pos, status, (pq2::ParseState *)state, passes);
+    else
+        hipLaunchKernelGGL(pq2::probe_kernel<false>, dim3(n_pages), dim3(64), 0, stream, (const pq2::PageDev *)pages,
+                           n_pages, (pq2::Resume *)resume, tile_page, run_pos, status, (pq2::ParseState *)state, passes);
     return hipGetLastError();
 }
 

@@ -39,11 +39,21 @@ constexpr uint32_t kScoutRow = 66;                          // table entries per
 constexpr uint32_t kScoutTable = kScoutSeg * kScoutRow;     // entries (of 2 bytes) per tile
 constexpr uint32_t kScoutEsc = 0x8000u;                     // entry: "decode the header at tile offset (entry & 0x7fff)"
 constexpr uint32_t kScoutNone = 0xffffffffu;                // a tile the chain does not enter / a chain that has ended
+constexpr uint32_t kScoutGaveUp = 0xfffffffeu;              // a chain whose exit was not worth finding out on a guess
+constexpr uint32_t kScoutGuessEscapes = 3;                  // escapes the resolve step follows for an entry that is a guess
 constexpr uint32_t kScoutLdsTiles = 2048;                   // pages of up to this many tiles are resolved in LDS
 constexpr uint32_t kScoutWin = kScoutTile + 64u;            // bytes of a tile the chase may touch
 constexpr uint32_t kScoutPanic = 0x80000000u, kScoutTerm = 0x40000000u, kScoutBad = 0x20000000u;
 constexpr uint32_t kScoutRunsMask = 0x1fffffffu;
 constexpr uint32_t kValueCap = 0x7fffffffu;
+#ifndef PQ2_SCOUT_BINS
+#define PQ2_SCOUT_BINS 1024
+#endif
+constexpr uint32_t kScoutBins = PQ2_SCOUT_BINS;             // vote counters per tile (exits that far apart share one)
+#ifndef PQ2_SCOUT_VOTERS
+#define PQ2_SCOUT_VOTERS 64
+#endif
+constexpr uint32_t kScoutVoters = PQ2_SCOUT_VOTERS;         // the offsets of the tile's first so many segments vote
 
 struct ScoutPage {
     uint32_t tile_base;  // batch-wide number of the page's first stream tile
@@ -69,6 +79,11 @@ __device__ __forceinline__ ScoutTiles scout_tiles(uint32_t *base, uint32_t n_sti
     return t;
 }
 __device__ __forceinline__ uint32_t table_slot(uint32_t off) { return (off & 31u) * kScoutRow + (off >> 5); }
+// probe_kernel (pq2_kernels.hip) has walked the whole page already: nothing is left for the scout kernels.  (Only
+// asked about pages with stream tiles: those have values, and the probe has written their state.)
+__device__ __forceinline__ bool scout_page_done(const ParseState *__restrict__ state, uint32_t page) {
+    return __builtin_amdgcn_readfirstlane(state[page].done) != 0u;
+}
 
 // ---------------------------------------------------------------------------
 // map: which page a stream tile belongs to
@@ -122,15 +137,17 @@ __device__ __forceinline__ void scout_segments(const PageDev &pg, const uint32_t
 // One wave per tile, four tiles per workgroup.
 __global__ __launch_bounds__(256) void scout_table_kernel(const PageDev *__restrict__ pages,
                                                           const ScoutPage *__restrict__ sp, uint32_t *__restrict__ tiles,
-                                                          uint16_t *__restrict__ table, uint32_t n_stiles) {
+                                                          uint16_t *__restrict__ table, uint32_t n_stiles,
+                                                          const ParseState *__restrict__ state) {
     __shared__ __attribute__((aligned(16))) uint16_t lds[4][kScoutTable];
-    __shared__ uint32_t votes[4][kScoutTile / 2u];  // two 16-bit counters per word
+    __shared__ uint32_t votes[4][kScoutBins / 2u];  // two 16-bit counters per word
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t g = blockIdx.x * 4u + wave;
     if (g >= n_stiles) return;
     const ScoutTiles t = scout_tiles(tiles, n_stiles);
     const uint32_t page = __builtin_amdgcn_readfirstlane(t.page[g]);
+    if (scout_page_done(state, page)) return;
     const PageDev pg = pages[page];
     const uint32_t t0 = (g - __builtin_amdgcn_readfirstlane(sp[page].tile_base)) * kScoutTile;
     uint16_t *const tbl = lds[wave];
@@ -152,24 +169,49 @@ __global__ __launch_bounds__(256) void scout_table_kernel(const PageDev *__restr
     {
         uint32_t *const vote = votes[wave];
 #pragma unroll
-        for (uint32_t i = 0; i < kScoutTile / 2u / 64u; ++i) vote[i * 64u + lane] = 0u;
+        for (uint32_t i = 0; i < kScoutBins / 2u / 64u; ++i) vote[i * 64u + lane] = 0u;
         wave_sync();
+        // (the offsets of a segment that leave the tile at the same place -- in a stretch of short runs, all of them --
+        // vote together)
+        auto cast = [&](uint32_t v, uint32_t times) {
+            if (v >= kScoutTile && v < 2u * kScoutTile && lane < kScoutVoters)
+                atomicAdd(&vote[((v - kScoutTile) & (kScoutBins - 1u)) >> 1], times << ((v & 1u) * 16u));
+        };
+        uint32_t same = tbl[lane], times = 1u;
 #pragma unroll 4
-        for (uint32_t i = 0; i < kScoutSeg; ++i) {
+        for (uint32_t i = 1; i < kScoutSeg; ++i) {
             const uint32_t v = tbl[i * kScoutRow + lane];
-            if (v >= kScoutTile && v < 2u * kScoutTile) atomicAdd(&vote[(v - kScoutTile) >> 1], 1u << ((v & 1u) * 16u));
+            if (v != same) {
+                cast(same, times);
+                same = v, times = 0u;
+            }
+            ++times;
         }
+        cast(same, times);
         wave_sync();
-        uint32_t best = 0;  // votes << 11 | offset in the next tile
+        uint32_t best = 0;  // votes << 10 | counter
 #pragma unroll
-        for (uint32_t i = 0; i < kScoutTile / 2u / 64u; ++i) {
-            const uint32_t at = lane * (kScoutTile / 2u / 64u) + i;
+        for (uint32_t i = 0; i < kScoutBins / 2u / 64u; ++i) {
+            const uint32_t at = lane * (kScoutBins / 2u / 64u) + i;
             const uint32_t word = vote[at];
-            best = max(best, ((word & 0xffffu) << 11) | (2u * at));
-            best = max(best, ((word >> 16) << 11) | (2u * at + 1u));
+            best = max(best, ((word & 0xffffu) << 10) | (2u * at));
+            best = max(best, ((word >> 16) << 10) | (2u * at + 1u));
         }
         best = __builtin_amdgcn_readlane(wave_inclusive_max(best), 63);
-        if (lane == 0) t.exit[g] = (best >> 11) >= 2u ? t0 + kScoutTile + (best & (kScoutTile - 1u)) : kScoutNone;
+        // the two exits that share the winning counter: the one more of the voters leave at
+        const uint32_t near = kScoutTile + (best & (kScoutBins - 1u)), far = near + kScoutBins;
+        uint32_t n_near = 0, n_far = 0;
+        if (lane < kScoutVoters) {
+#pragma unroll 4
+            for (uint32_t i = 0; i < kScoutSeg; ++i) {
+                const uint32_t v = tbl[i * kScoutRow + lane];
+                n_near += v == near ? 1u : 0u;
+                n_far += v == far ? 1u : 0u;
+            }
+        }
+        n_near = __builtin_amdgcn_readlane(wave_inclusive_sum(n_near), 63);
+        n_far = __builtin_amdgcn_readlane(wave_inclusive_sum(n_far), 63);
+        if (lane == 0) t.exit[g] = max(n_near, n_far) >= 2u ? t0 + (n_far > n_near ? far : near) : kScoutNone;
     }
     // the table as it lies in LDS: kScoutTable * 2 = 4224 bytes = 264 pieces of 16
     u32x4 *const dst = (u32x4 *)(table + (size_t)g * kScoutTable);
@@ -186,13 +228,16 @@ __global__ __launch_bounds__(256) void scout_table_kernel(const PageDev *__restr
 // ---------------------------------------------------------------------------
 // Where the chain that enters a tile at a-offset x leaves that tile: the a-offset of the first header in a later
 // tile, or kScoutNone if the chain ends first (end of the stream, or a header on which the reference panics).
+// Every escape costs two trips to memory, and a chain that starts at a wrong guess inside a bit-packed payload
+// may go through many: after `escapes` of them the answer is kScoutGaveUp.
 __device__ __forceinline__ uint32_t scout_leave(const PageDev &pg, const __amdgpu_buffer_rsrc_t rsrc, const uint32_t end,
-                                                const uint16_t *__restrict__ page_table, uint32_t x) {
+                                                const uint16_t *__restrict__ page_table, uint32_t x, uint32_t escapes) {
     const uint32_t tile = x / kScoutTile;
     auto rd = [&](uint32_t a) -> uint32_t { return __builtin_amdgcn_raw_buffer_load_b32(rsrc, a, 0, 0); };
     for (;;) {
         const uint32_t v = page_table[(size_t)tile * kScoutTable + table_slot(x % kScoutTile)];
         if ((v & kScoutEsc) == 0u) return tile * kScoutTile + v;
+        if (escapes-- == 0u) return kScoutGaveUp;
         const RunInfo run = decode_run(rd, tile * kScoutTile + (v & 0x7fffu), end, pg.num_bits, 0xffffffffu);
         if (run.kind >= kEnd) return kScoutNone;
         if (run.next / kScoutTile != tile) return run.next;
@@ -206,14 +251,19 @@ __global__ __launch_bounds__(256) void scout_resolve_kernel(const PageDev *__res
                                                             const ScoutPage *__restrict__ sp, uint32_t n_pages,
                                                             const uint16_t *__restrict__ table,
                                                             uint32_t *__restrict__ tiles, uint32_t n_stiles,
-                                                            uint32_t *__restrict__ scratch) {
+                                                            uint32_t *__restrict__ scratch,
+                                                            uint32_t *__restrict__ rounds_out,
+                                                            const ParseState *__restrict__ state) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_words[];
     __shared__ uint32_t changed;
     const uint32_t page = blockIdx.x;
     if (page >= n_pages) return;
     const ScoutPage s = sp[page];
     const uint32_t n = s.n_tiles;
-    if (n == 0u) return;
+    if (n == 0u || scout_page_done(state, page)) {
+        if (threadIdx.x == 0) rounds_out[page] = 0u;
+        return;
+    }
     const PageDev pg = pages[page];
     const ScoutTiles t = scout_tiles(tiles, n_stiles);
     const uint32_t delta = (uint32_t)(pg.in_addr & 15u);
@@ -225,31 +275,42 @@ __global__ __launch_bounds__(256) void scout_resolve_kernel(const PageDev *__res
     uint32_t *const arrays = n <= kScoutLdsTiles ? lds_words : scratch + 6 * ((size_t)s.tile_base + 8u * page);
     uint32_t *const cand = arrays;                 // where tile k is entered, as far as is known
     uint32_t *const leave = arrays + stride;       // where the chain from cand[k] leaves tile k
-    uint32_t *const flag = arrays + 2 * stride;    // bit 0: leave[k] is out of date; bit 1: tile k is reached
+    uint32_t *const flag = arrays + 2 * stride;    // bit 0: leave[k] is out of date; bit 1: tile k is reached;
+    //                                                bit 2: tile k was reached once: its chain is followed to the end
     uint32_t *jump[2] = {arrays + 3 * stride, arrays + 4 * stride};  // the tile 2^r hops behind tile k (n: none)
     uint32_t *const offer = arrays + 5 * stride;   // who hands tile k its entry: reached << 31 | (tile + 1)
     const uint32_t tid = threadIdx.x;
-    auto tile_of = [&](uint32_t x) { return x == kScoutNone ? n : min(x / kScoutTile, n); };
+    auto tile_of = [&](uint32_t x) { return x >= kScoutGaveUp ? n : min(x / kScoutTile, n); };
 
     // first guesses: the page's first byte; elsewhere what the table step saw most chains of the tile before arrive
     // at, or the tile's first byte
     for (uint32_t k = tid; k < n; k += 256u) {
         uint32_t x = k == 0u ? delta : k * kScoutTile;
+        bool guess = k != 0u;
         if (k != 0u) {
             const uint32_t hint = t.exit[s.tile_base + k - 1u];
-            if (hint != kScoutNone && hint / kScoutTile == k) x = hint;
+            if (hint != kScoutNone && hint / kScoutTile == k) x = hint, guess = false;
         }
         cand[k] = x;
-        flag[k] = 1u;
+        // (the first byte of a tile is rarely a header: such a guess is not followed, the tile waits for an offer)
+#ifdef PQ2_SCOUT_EVAL_GUESSES
+        guess = false;
+#endif
+        leave[k] = kScoutGaveUp;
+        flag[k] = guess ? 0u : 1u;
     }
     uint32_t rounds = 0;
     while ((1u << rounds) < n) ++rounds;
-    for (uint32_t iter = 0; iter <= n; ++iter) {
+    uint32_t iter_count = 0;
+    for (uint32_t iter = 0; iter <= 2u * n; ++iter) {
+        ++iter_count;
         __syncthreads();
         if (tid == 0) changed = 0u;
         for (uint32_t k = tid; k < n; k += 256u) {
-            if (flag[k] & 1u) leave[k] = scout_leave(pg, rsrc, end, page_table, cand[k]);
-            flag[k] = k == 0u ? 2u : 0u;
+            const uint32_t f = flag[k];
+            if (f & 1u)
+                leave[k] = scout_leave(pg, rsrc, end, page_table, cand[k], (k == 0u || (f & 4u)) ? 0xffffffffu : kScoutGuessEscapes);
+            flag[k] = (k == 0u ? 2u : 0u) | (f & 4u);
             jump[0][k] = tile_of(leave[k]);
             offer[k] = 0u;
         }
@@ -261,7 +322,7 @@ __global__ __launch_bounds__(256) void scout_resolve_kernel(const PageDev *__res
             uint32_t *const to = jump[(r & 1u) ^ 1u];
             for (uint32_t k = tid; k <= n; k += 256u) {
                 const uint32_t j = from[k];
-                if (flag[k] & 2u) flag[j] = 2u;  // (tile n stands for "nowhere")
+                if (flag[k] & 2u) flag[j] |= 2u;  // (tile n stands for "nowhere")
                 to[k] = from[j];
             }
             __syncthreads();
@@ -272,6 +333,10 @@ __global__ __launch_bounds__(256) void scout_resolve_kernel(const PageDev *__res
         for (uint32_t k = tid; k < n; k += 256u) {
             const uint32_t m = tile_of(leave[k]);
             if (m < n) atomicMax(&offer[m], ((flag[k] & 2u) << 30) | (k + 1u));
+            if ((flag[k] & 2u) && leave[k] == kScoutGaveUp) {  // reached after all: the whole chain next time
+                flag[k] |= 5u;
+                changed = 1u;
+            }
         }
         __syncthreads();
         for (uint32_t m = tid; m < n; m += 256u) {
@@ -287,6 +352,7 @@ __global__ __launch_bounds__(256) void scout_resolve_kernel(const PageDev *__res
         __syncthreads();
         if (changed == 0u) break;  // every reached tile is entered where its predecessor leaves
     }
+    if (tid == 0) rounds_out[page] = iter_count;
     for (uint32_t k = tid; k < n; k += 256u) {
         const bool reached = (flag[k] & 2u) != 0u;
         t.entry[s.tile_base + k] = reached ? cand[k] : kScoutNone;
@@ -302,13 +368,15 @@ __global__ __launch_bounds__(256) void scout_resolve_kernel(const PageDev *__res
 template <bool kWide>
 __global__ __launch_bounds__(256) void scout_count_kernel(const PageDev *__restrict__ pages,
                                                           const ScoutPage *__restrict__ sp, uint32_t *__restrict__ tiles,
-                                                          uint16_t *__restrict__ table, uint32_t n_stiles) {
+                                                          uint16_t *__restrict__ table, uint32_t n_stiles,
+                                                          const ParseState *__restrict__ state) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[4][kScoutWin];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t g = blockIdx.x * 4u + wave;
     if (g >= n_stiles) return;
     const ScoutTiles tl = scout_tiles(tiles, n_stiles);
+    if (scout_page_done(state, __builtin_amdgcn_readfirstlane(tl.page[g]))) return;
     uint32_t pos = __builtin_amdgcn_readfirstlane(tl.entry[g]);
     if (pos == kScoutNone) {
         if (lane == 0) tl.vals[g] = 0u, tl.runs[g] = 0u;
@@ -416,7 +484,7 @@ __device__ __forceinline__ Resume *scout_resume_entry(const PageDev &pg, Resume 
 // Blocks [from, n_blocks) of the page lie behind the last value the stream holds: zeros (mod.rs:95); closes the
 // header list after `n_runs` entries and gives the page its status.  All lanes of one wave.
 __device__ __forceinline__ void scout_close_page(const PageDev &pg, const uint32_t page, Resume *resume, uint32_t *run_pos,
-                                                 int32_t *status, ParseState *state, const uint32_t produced,
+                                                 int32_t *status, const uint32_t produced,
                                                  const uint32_t n_runs, const int32_t st, const uint32_t lane) {
     const uint32_t n_blocks = (pg.num_values + kBlockValues - 1u) / kBlockValues;
     Resume e;
@@ -428,10 +496,7 @@ __device__ __forceinline__ void scout_close_page(const PageDev &pg, const uint32
         *scout_resume_entry(pg, resume, b) = e;
     if (lane == 0) {
         run_pos[pg.run_base + n_runs] = kEndPos;
-        status[page] = st;
-        ParseState ps;
-        ps.pos = 0, ps.produced = produced, ps.n_runs = n_runs, ps.done = 1u;
-        state[page] = ps;
+        status[page] = st;  // (the page's ParseState stays as the probe left it: other waves are still asking it)
     }
 }
 
@@ -441,7 +506,7 @@ __global__ __launch_bounds__(256) void scout_scan_kernel(const PageDev *__restri
                                                          uint32_t *__restrict__ tiles, uint32_t n_stiles,
                                                          ScoutFin *__restrict__ fin, Resume *__restrict__ resume,
                                                          uint32_t *__restrict__ tile_page, uint32_t *__restrict__ run_pos,
-                                                         int32_t *__restrict__ status, ParseState *__restrict__ state) {
+                                                         int32_t *__restrict__ status, const ParseState *__restrict__ state) {
     __shared__ uint32_t wave_vals[4], wave_runs[4], first_full, last_reached, any_flags;
     const uint32_t page = blockIdx.x;
     if (page >= n_pages) return;
@@ -456,9 +521,10 @@ __global__ __launch_bounds__(256) void scout_scan_kernel(const PageDev *__restri
     for (uint32_t k = tid; k < (n + kTileValues - 1u) / kTileValues; k += 256u) tile_page[pg.tile_number(k)] = page;
     const ScoutPage s = sp[page];
     if (s.n_tiles == 0u) {  // decoder.rs:31-37: nothing to iterate
-        if (wave == 0u) scout_close_page(pg, page, resume, run_pos, status, state, 0u, 0u, 0, lane);
+        if (wave == 0u) scout_close_page(pg, page, resume, run_pos, status, 0u, 0u, 0, lane);
         return;
     }
+    if (scout_page_done(state, page)) return;
     const ScoutTiles t = scout_tiles(tiles, n_stiles);
     if (tid == 0) first_full = kScoutNone, last_reached = 0u, any_flags = 0u;
     uint32_t carry_vals = 0, carry_runs = 0;
@@ -510,14 +576,15 @@ __global__ __launch_bounds__(256) void scout_place_kernel(const PageDev *__restr
                                                           const uint16_t *__restrict__ table, uint32_t n_stiles,
                                                           const ScoutFin *__restrict__ fin, Resume *__restrict__ resume,
                                                           uint32_t *__restrict__ run_pos, int32_t *__restrict__ status,
-                                                          ParseState *__restrict__ state) {
+                                                          const ParseState *__restrict__ state) {
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t g = blockIdx.x * 4u + wave;
     if (g >= n_stiles) return;
     const ScoutTiles t = scout_tiles(tiles, n_stiles);
-    if (__builtin_amdgcn_readfirstlane(t.entry[g]) == kScoutNone) return;
     const uint32_t page = __builtin_amdgcn_readfirstlane(t.page[g]);
+    if (scout_page_done(state, page)) return;
+    if (__builtin_amdgcn_readfirstlane(t.entry[g]) == kScoutNone) return;
     const PageDev pg = pages[page];
     const uint32_t n = pg.num_values;
     uint32_t produced = __builtin_amdgcn_readfirstlane(t.base_vals[g]);
@@ -590,7 +657,7 @@ __global__ __launch_bounds__(256) void scout_place_kernel(const PageDev *__restr
     int32_t st = 0;
     if (produced < n && (flags & kScoutPanic)) st = 5;  // PQ2_REFERENCE_WOULD_PANIC
     if (flags & kScoutBad) st = 6;                      // PQ2_DEVICE_ERROR: table and walk disagree
-    scout_close_page(pg, page, resume, run_pos, status, state, min(produced, n), n_runs, st, lane);
+    scout_close_page(pg, page, resume, run_pos, status, min(produced, n), n_runs, st, lane);
 }
 
 }  // namespace pq2
@@ -600,38 +667,52 @@ __global__ __launch_bounds__(256) void scout_place_kernel(const PageDev *__restr
 // the tables, the per-tile words, the per-page closing records and the resolve step's arrays for large pages.
 extern "C" uint32_t pq2_scout_tile_bytes() { return pq2::kScoutTile; }
 extern "C" size_t pq2_scout_table_bytes(uint64_t n_stiles) { return (size_t)n_stiles * pq2::kScoutTable * 2u; }
+// where, in `words`, the resolve step leaves the number of rounds it took for every page (diagnostics)
+extern "C" size_t pq2_scout_rounds_at(uint64_t n_stiles, uint64_t n_pages) { return (7u * (size_t)n_stiles + 2u * (size_t)n_pages) * 4u; }
 extern "C" size_t pq2_scout_words_bytes(uint64_t n_stiles, uint64_t n_pages) {
-    return (7u * (size_t)n_stiles + 2u * (size_t)n_pages + 6u * ((size_t)n_stiles + 8u * (size_t)n_pages) + 16u) * 4u;
+    return (7u * (size_t)n_stiles + 3u * (size_t)n_pages + 6u * ((size_t)n_stiles + 8u * (size_t)n_pages) + 16u) * 4u;
 }
 
 // The header walk of a whole batch.  `spages`: n_pages ScoutPage records (device); `table`, `words`: scratch of
 // the sizes above.  Leaves resume / tile_page / run_pos / status / state as parse_kernel's single round does.
+extern "C" hipError_t pq2_launch_probe(const void *pages, uint32_t n_pages, void *resume, uint32_t *tile_page,
+                                       uint32_t *run_pos, int32_t *status, void *state, uint32_t passes, uint32_t max_bits,
+                                       hipStream_t stream);  // pq2_kernels.hip
+#ifndef PQ2_SCOUT_PROBE_PASSES
+#define PQ2_SCOUT_PROBE_PASSES 2
+#endif
 extern "C" hipError_t pq2_launch_scout(const void *pages, const void *spages, uint32_t n_pages, uint32_t n_stiles,
                                        void *table, void *words, void *resume, uint32_t *tile_page, uint32_t *run_pos,
                                        int32_t *status, void *state, uint32_t max_bits, hipStream_t stream) {
     using namespace pq2;
     if (n_pages == 0) return hipSuccess;
+    // pages of few runs are done by a short ordinary walk (it also gives every page with values its ParseState)
+    hipError_t e = pq2_launch_probe(pages, n_pages, resume, tile_page, run_pos, status, state, PQ2_SCOUT_PROBE_PASSES,
+                                    max_bits, stream);
+    if (e != hipSuccess) return e;
+    const ParseState *done = (const ParseState *)state;
     const PageDev *pg = (const PageDev *)pages;
     const ScoutPage *sp = (const ScoutPage *)spages;
     uint32_t *tiles = (uint32_t *)words;
     ScoutFin *fin = (ScoutFin *)(tiles + 7u * (size_t)n_stiles);
-    uint32_t *scratch = (uint32_t *)(fin + n_pages);
+    uint32_t *rounds = (uint32_t *)(fin + n_pages);  // per page: rounds of the resolve step (pq2_scout_rounds_at)
+    uint32_t *scratch = rounds + n_pages;
     uint16_t *tbl = (uint16_t *)table;
     const uint32_t tile_groups = (n_stiles + 3u) / 4u;
     if (n_stiles != 0u) {
         hipLaunchKernelGGL(scout_map_kernel, dim3(n_pages), dim3(256), 0, stream, sp, n_pages, tiles, n_stiles);
-        hipLaunchKernelGGL(scout_table_kernel, dim3(tile_groups), dim3(256), 0, stream, pg, sp, tiles, tbl, n_stiles);
+        hipLaunchKernelGGL(scout_table_kernel, dim3(tile_groups), dim3(256), 0, stream, pg, sp, tiles, tbl, n_stiles, done);
         hipLaunchKernelGGL(scout_resolve_kernel, dim3(n_pages), dim3(256), 6u * (kScoutLdsTiles + 8u) * 4u, stream, pg, sp,
-                           n_pages, tbl, tiles, n_stiles, scratch);
+                           n_pages, tbl, tiles, n_stiles, scratch, rounds, done);
         if (max_bits > 16u)
-            hipLaunchKernelGGL(scout_count_kernel<true>, dim3(tile_groups), dim3(256), 0, stream, pg, sp, tiles, tbl, n_stiles);
+            hipLaunchKernelGGL(scout_count_kernel<true>, dim3(tile_groups), dim3(256), 0, stream, pg, sp, tiles, tbl, n_stiles, done);
         else
-            hipLaunchKernelGGL(scout_count_kernel<false>, dim3(tile_groups), dim3(256), 0, stream, pg, sp, tiles, tbl, n_stiles);
+            hipLaunchKernelGGL(scout_count_kernel<false>, dim3(tile_groups), dim3(256), 0, stream, pg, sp, tiles, tbl, n_stiles, done);
     }
     hipLaunchKernelGGL(scout_scan_kernel, dim3(n_pages), dim3(256), 0, stream, pg, sp, n_pages, tiles, n_stiles, fin,
-                       (Resume *)resume, tile_page, run_pos, status, (ParseState *)state);
+                       (Resume *)resume, tile_page, run_pos, status, done);
     if (n_stiles != 0u)
         hipLaunchKernelGGL(scout_place_kernel, dim3(tile_groups), dim3(256), 0, stream, pg, sp, tiles, tbl, n_stiles, fin,
-                           (Resume *)resume, run_pos, status, (ParseState *)state);
+                           (Resume *)resume, run_pos, status, done);
     return hipGetLastError();
 }

@@ -54,6 +54,10 @@ constexpr uint32_t kScoutBins = PQ2_SCOUT_BINS;             // vote counters per
 #define PQ2_SCOUT_VOTERS 64
 #endif
 constexpr uint32_t kScoutVoters = PQ2_SCOUT_VOTERS;         // the offsets of the tile's first so many segments vote
+#ifndef PQ2_SCOUT_DENSE
+#define PQ2_SCOUT_DENSE 40
+#endif
+constexpr uint32_t kScoutDense = PQ2_SCOUT_DENSE;           // headers per tile from which the count step works lane-parallel
 
 struct ScoutPage {
     uint32_t tile_base;  // batch-wide number of the page's first stream tile
@@ -100,33 +104,51 @@ __global__ __launch_bounds__(256) void scout_map_kernel(const ScoutPage *__restr
 // ---------------------------------------------------------------------------
 // table
 // ---------------------------------------------------------------------------
-// Lane l: for every offset i of segment l of the tile at a-offset t0, where the chain of headers that starts at
-// i leaves the segment -- a tile offset >= 32 (l + 1), or an escape -- into tbl[i * kScoutRow + l].
-__device__ __forceinline__ void scout_segments(const PageDev &pg, const uint32_t t0, uint16_t *tbl, const uint32_t lane) {
-    const uint32_t delta = (uint32_t)(pg.in_addr & 15u);
-    const uint32_t end = delta + pg.in_len;
-    const uint32_t w = pg.num_bits;
-    const uint32_t rb = ceil8(w);
-    const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(pg.in_addr - delta, (end + 3u) & ~3u);
-    const uint32_t seg_rel = lane * kScoutSeg;
-    const uint32_t seg_a = t0 + seg_rel;
+// The bytes of a lane's segment and the first four behind it (what a header in the segment's last byte may need).
+struct SegBytes {
+    uint32_t d[9];
+};
+__device__ __forceinline__ SegBytes scout_load_segment(const __amdgpu_buffer_rsrc_t rsrc, const uint32_t seg_a) {
     const u32x4 lo4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, seg_a, 0, 0);
     const u32x4 hi4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, seg_a + 16u, 0, 0);
     const uint32_t d8 = __builtin_amdgcn_raw_buffer_load_b32(rsrc, seg_a + 32u, 0, 0);
-    const uint32_t d[9] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w, d8};
+    const SegBytes sb = {{lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w, d8}};
+    return sb;
+}
+// The header that would begin at byte `i` (a constant) of the segment, read as one of one or two bytes
+// (uleb128.rs:3-23): its bytes, the bytes of its run (decoder.rs:48-63) and the values the run holds (mod.rs:41-64).
+struct SegHeader {
+    uint32_t c, body, count;
+    bool longer;  // the varint has three bytes or more: not this one
+};
+__device__ __forceinline__ SegHeader scout_header(const SegBytes &sb, const int i, const uint32_t w, const uint32_t rb) {
+    const uint32_t b0 = (sb.d[i >> 2] >> ((i & 3) * 8)) & 0xffu;
+    const uint32_t b1 = (sb.d[(i + 1) >> 2] >> (((i + 1) & 3) * 8)) & 0xffu;
+    const bool two = (b0 & 0x80u) != 0u;
+    const uint32_t ind = two ? ((b0 & 0x7fu) | (b1 << 7)) : b0;
+    SegHeader h;
+    h.c = two ? 2u : 1u;
+    h.body = (ind & 1u) ? (ind >> 1) * w : rb;
+    h.count = (ind & 1u) ? (ind >> 1) * 8u : (ind >> 1);
+    h.longer = two && (b1 & 0x80u) != 0u;
+    return h;
+}
+
+// Lane l: for every offset i of segment l of the tile at a-offset t0, where the chain of headers that starts at
+// i leaves the segment -- a tile offset >= 32 (l + 1), or an escape -- into tbl[i * kScoutRow + l].
+__device__ __forceinline__ void scout_segments(const SegBytes &sb, const uint32_t t0, const uint32_t end, const uint32_t w,
+                                               uint16_t *tbl, const uint32_t lane) {
+    const uint32_t rb = ceil8(w);
+    const uint32_t seg_rel = lane * kScoutSeg;
+    const uint32_t seg_a = t0 + seg_rel;
 #pragma unroll
     for (int i = (int)kScoutSeg - 1; i >= 0; --i) {
-        const uint32_t b0 = (d[i >> 2] >> ((i & 3) * 8)) & 0xffu;
-        const uint32_t b1 = (d[(i + 1) >> 2] >> (((i + 1) & 3) * 8)) & 0xffu;
-        const bool two = (b0 & 0x80u) != 0u;
-        const uint32_t ind = two ? ((b0 & 0x7fu) | (b1 << 7)) : b0;  // uleb128.rs:3-23, one or two bytes
-        const uint32_t c = two ? 2u : 1u;
-        const uint32_t body = (ind & 1u) ? (ind >> 1) * w : rb;      // decoder.rs:48-63
-        const uint32_t q = seg_a + (uint32_t)i + c;                  // the byte behind the header
-        const uint32_t nxt = (uint32_t)i + c + body;                 // the next header, from the segment's start
-        const uint32_t far = seg_rel + nxt;                          // ... from the tile's start
+        const SegHeader h = scout_header(sb, i, w, rb);
+        const uint32_t q = seg_a + (uint32_t)i + h.c;      // the byte behind the header
+        const uint32_t nxt = (uint32_t)i + h.c + h.body;   // the next header, from the segment's start
+        const uint32_t far = seg_rel + nxt;                // ... from the tile's start
         // the short path of decode_run: a header of one or two bytes whose run lies inside the stream
-        const bool plain = !(two && (b1 & 0x80u)) && q < end && body <= end - q && far < kScoutEsc;
+        const bool plain = !h.longer && q < end && h.body <= end - q && far < kScoutEsc;
         const uint32_t inside = tbl[(nxt & 31u) * kScoutRow + lane];  // where the chain from nxt leaves (if nxt < 32)
         uint32_t v = nxt < kScoutSeg ? inside : far;
         if (!plain) v = kScoutEsc | (seg_rel + (uint32_t)i);
@@ -151,15 +173,35 @@ __global__ __launch_bounds__(256) void scout_table_kernel(const PageDev *__restr
     const PageDev pg = pages[page];
     const uint32_t t0 = (g - __builtin_amdgcn_readfirstlane(sp[page].tile_base)) * kScoutTile;
     uint16_t *const tbl = lds[wave];
-    scout_segments(pg, t0, tbl, lane);
+    {
+        const uint32_t delta = (uint32_t)(pg.in_addr & 15u);
+        const uint32_t end = delta + pg.in_len;
+        const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(pg.in_addr - delta, (end + 3u) & ~3u);
+        scout_segments(scout_load_segment(rsrc, t0 + lane * kScoutSeg), t0, end, pg.num_bits, tbl, lane);
+    }
     wave_sync();
-    // From the last segment but one to the first: an entry that leaves its segment inside the tile takes over the
-    // entry of the offset it lands on, which is final already (that offset lies in a later segment).
-    for (int s = 62; s >= 0; --s) {
-        if (lane < kScoutSeg) {
-            const uint32_t at = lane * kScoutRow + (uint32_t)s;
+    // An entry that leaves its segment inside the tile takes over the entry of the offset it lands on, once that
+    // one is final.  In two levels, so that all lanes work: first inside every group of 8 segments, from each group's
+    // last segment but one to its first (all 8 groups at a time: 256 entries a step), then group by group from the
+    // last but one to the first (the 256 entries of a group a step).
+    static_assert(kScoutTile == 8u * 8u * kScoutSeg && kScoutSeg == 32u, "8 groups of 8 segments of 32 offsets");
+    for (int j = 6; j >= 0; --j) {
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) {
+            const uint32_t group = (lane >> 5) + 2u * k;
+            const uint32_t at = (lane & 31u) * kScoutRow + 8u * group + (uint32_t)j;
             const uint32_t v = tbl[at];
-            if (v < kScoutTile) tbl[at] = tbl[table_slot(v)];
+            if (v < 256u * (group + 1u)) tbl[at] = tbl[table_slot(v)];  // lands in a later segment of its group
+        }
+        wave_sync();
+    }
+    for (int group = 6; group >= 0; --group) {
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) {
+            const uint32_t e = lane + 64u * k;  // entry e of the group: offset e & 31 of its segment e >> 5
+            const uint32_t at = (e & 31u) * kScoutRow + 8u * (uint32_t)group + (e >> 5);
+            const uint32_t v = tbl[at];
+            if (v < kScoutTile) tbl[at] = tbl[table_slot(v)];  // lands in a later group
         }
         wave_sync();
     }
@@ -211,7 +253,10 @@ __global__ __launch_bounds__(256) void scout_table_kernel(const PageDev *__restr
         }
         n_near = __builtin_amdgcn_readlane(wave_inclusive_sum(n_near), 63);
         n_far = __builtin_amdgcn_readlane(wave_inclusive_sum(n_far), 63);
-        if (lane == 0) t.exit[g] = max(n_near, n_far) >= 2u ? t0 + (n_far > n_near ? far : near) : kScoutNone;
+        if (lane == 0) {
+            t.exit[g] = max(n_near, n_far) >= 2u ? t0 + (n_far > n_near ? far : near) : kScoutNone;
+            t.vals[g] = max(n_near, n_far);  // about as many headers as the page's chain has in this tile (count step)
+        }
     }
     // the table as it lies in LDS: kScoutTable * 2 = 4224 bytes = 264 pieces of 16
     u32x4 *const dst = (u32x4 *)(table + (size_t)g * kScoutTable);
@@ -371,6 +416,7 @@ __global__ __launch_bounds__(256) void scout_count_kernel(const PageDev *__restr
                                                           uint16_t *__restrict__ table, uint32_t n_stiles,
                                                           const ParseState *__restrict__ state) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[4][kScoutWin];
+    __shared__ __attribute__((aligned(16))) uint16_t seg_lds[4][kScoutTable];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t g = blockIdx.x * 4u + wave;
@@ -392,10 +438,55 @@ __global__ __launch_bounds__(256) void scout_count_kernel(const PageDev *__restr
     const uint32_t rb = ceil8(w);
     const uint32_t rb_mask = rb < 4 ? (1u << (rb * 8u)) - 1u : ~0u;
     const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(pg.in_addr - delta, (end + 3u) & ~3u);
+    uint16_t *const list = table + (size_t)g * kScoutTable;  // the tile's table is not needed any more
+
+    uint32_t vals = 0, listed = 0, term = 0;
+    // ---- a tile with many headers: all lanes at once --------------------------------------------------------
+    // Lane l finds, as the table step does, where the chains inside segment l lead; one walk from segment to
+    // segment (at most 64 steps instead of one per header) then tells every segment where the page's chain
+    // enters it, and each lane follows the chain through its own 32 bytes.  At the first header the table step
+    // would leave to the exact decoder (the end of the stream is one) the walk below takes over.
+    // (The table step's count of the chains that leave the tile together says how many headers to expect; it sees
+    // none in the tile that holds the end of the stream.)
+    if (__builtin_amdgcn_readfirstlane(tl.vals[g]) >= kScoutDense || tile_end >= end) {
+        uint16_t *const tbl = seg_lds[wave];
+        const SegBytes sb = scout_load_segment(rsrc, t0 + lane * kScoutSeg);
+        scout_segments(sb, t0, end, w, tbl, lane);
+        wave_sync();
+        uint32_t x = pos - t0, mine = kScoutSeg;  // mine: the offset at which the chain enters this lane's segment
+        uint32_t stop = kScoutSeg;                // ... and the offset of its segment from which the lane keeps out
+        while (x < kScoutTile) {
+            if (lane == (x >> 5)) mine = x & 31u;
+            const uint32_t v = __builtin_amdgcn_readfirstlane((uint32_t)tbl[table_slot(x)]);
+            if (v & kScoutEsc) {
+                x = v & 0x7fffu;  // in the same segment, at or behind the entry
+                if (lane == (x >> 5)) stop = x & 31u;
+                break;
+            }
+            x = v;
+        }
+        uint32_t at = mine, held = 0, sum = 0;  // held: bit i = a run that holds values begins at byte i
+#pragma unroll
+        for (int i = 0; i < (int)kScoutSeg; ++i) {
+            const SegHeader h = scout_header(sb, i, w, rb);
+            const bool hit = at == (uint32_t)i && (uint32_t)i < stop;
+            at = hit ? (uint32_t)i + h.c + h.body : at;
+            held |= (hit && h.count != 0u) ? 1u << i : 0u;
+            sum += hit ? h.count : 0u;  // < 32 * 2^16
+        }
+        const uint32_t n_held = (uint32_t)__popc(held);
+        const uint32_t upto = wave_inclusive_sum(n_held);
+        uint32_t slot = upto - n_held;
+        for (uint32_t m = held; m != 0u; m &= m - 1u) list[slot++] = (uint16_t)(lane * kScoutSeg + (uint32_t)__builtin_ctz(m));
+        vals = min(__builtin_amdgcn_readlane(wave_inclusive_sum(sum), 63), kValueCap);
+        listed = __builtin_amdgcn_readlane(upto, 63);
+        pos = __builtin_amdgcn_readfirstlane(t0 + x);  // behind the tile, or the header that is left to the walk
+    }
+
     uint8_t *const win = lds[wave];
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)win;
     static_assert(kScoutWin == 2u * 1024u + 64u, "the window is loaded in two rounds and four pieces");
-    {
+    if (pos < tile_end) {
         const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rsrc, t0 + lane * 16u, 0, 0);
         const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rsrc, t0 + 1024u + lane * 16u, 0, 0);
         u32x4 c = {0u, 0u, 0u, 0u};
@@ -406,9 +497,7 @@ __global__ __launch_bounds__(256) void scout_count_kernel(const PageDev *__restr
         wave_sync();
     }
     auto rd = [&](uint32_t a) -> uint32_t { return __builtin_amdgcn_readfirstlane(*(const uint32_t *)&win[a - t0]); };
-    uint16_t *const list = table + (size_t)g * kScoutTable;  // the tile's table is not needed any more
 
-    uint32_t vals = 0, listed = 0, term = 0;
     while (pos < tile_end && term == 0u) {
         // ---- chase: park up to 64 runs, record i in lane i (see PQ2_CHASE) ---------------------------------
         uint32_t r_pos = 0, r_lo = 0, r_hi = 0, r_info = 0;
@@ -679,7 +768,7 @@ extern "C" hipError_t pq2_launch_probe(const void *pages, uint32_t n_pages, void
                                        uint32_t *run_pos, int32_t *status, void *state, uint32_t passes, uint32_t max_bits,
                                        hipStream_t stream);  // pq2_kernels.hip
 #ifndef PQ2_SCOUT_PROBE_PASSES
-#define PQ2_SCOUT_PROBE_PASSES 2
+#define PQ2_SCOUT_PROBE_PASSES 1
 #endif
 extern "C" hipError_t pq2_launch_scout(const void *pages, const void *spages, uint32_t n_pages, uint32_t n_stiles,
                                        void *table, void *words, void *resume, uint32_t *tile_page, uint32_t *run_pos,

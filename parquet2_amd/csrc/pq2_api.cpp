@@ -47,6 +47,11 @@ int32_t pq2_noalloc_setup(int32_t device, uint8_t **out);  // pq2_noalloc.hip
 hipError_t pq2_launch_ring(const void *pages, uint32_t n_pages, int32_t *status, uint32_t *cu_tickets, uint32_t max_bits,
                            const uint32_t *tile_mask, hipStream_t stream);  // pq2_ring.hip
 uint32_t pq2_ring_ticket_bytes();
+uint32_t pq2_ring_dict_max_bits();  // pq2_ring_dict.hip
+uint32_t pq2_ring_dict_max_bytes();
+hipError_t pq2_launch_ring_dict(const void *pages, uint32_t n_pages, int32_t *status, uint32_t *cu_tickets,
+                                const uint32_t *tile_mask, const void *dicts, uint32_t value_words, uint32_t max_dict_bytes,
+                                hipStream_t stream);
 uint32_t pq2_scout_tile_bytes();  // pq2_scout.hip
 size_t pq2_scout_table_bytes(uint64_t n_stiles);
 size_t pq2_scout_words_bytes(uint64_t n_stiles, uint64_t n_pages);
@@ -133,6 +138,13 @@ struct TileMask {
 };
 
 // What pq2_decode_raw_pages_v1_device adds to a batch: front_kernel patches the uploaded stream descriptors.
+// What pq2_decode_dict_batch_device adds to a batch when the dictionary lookup happens inside ring_kernel: the
+// per-page records (device) and the dictionaries' size.
+struct FusedDict {
+    const void *d_dicts;
+    uint32_t value_words, max_dict_bytes;
+};
+
 struct FrontJob {
     const void *d_raw;
     uint32_t n_pages;
@@ -277,11 +289,16 @@ int32_t upload_block(pq2_ctx *ctx, size_t bytes, hipStream_t stream) {
     return PQ2_OK;
 }
 
+// Does a batch of `n_pages` pages whose streams' addresses the host knows go through ring_kernel?
+bool takes_ring(const pq2_ctx *ctx, uint64_t n_pages) {
+    return ctx->mode == pq2_ctx::kRing || (ctx->mode == pq2_ctx::kAuto && n_pages >= kScoutMaxPages);
+}
+
 // Validates the batch, builds the device descriptors in pinned memory, uploads
 // them and enqueues parse + expand on `stream`.
 int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const pq2_page_desc *descs, uint64_t n_pages,
                       uint32_t *d_out, uint64_t out_values, hipStream_t stream, const FrontJob *front = nullptr,
-                      uint32_t min_max_bits = 0, const TileMask *mask = nullptr) {
+                      uint32_t min_max_bits = 0, const TileMask *mask = nullptr, const FusedDict *fused = nullptr) {
     if (n_pages > 0x7fffffffull) return fail(ctx, PQ2_INVALID_PARAMETER, "too many pages in one batch");
     if (n_pages > 0 && !descs) return fail(ctx, PQ2_INVALID_PARAMETER, "descs is NULL");
     // the device-side metadata and the Resume table are shared by consecutive batches: stream order
@@ -349,8 +366,10 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
     // read; fewer pages: the tiles of all pages share the whole GPU
     // few pages: no page's walk has another page's expansion to hide behind, so the walk itself is spread over
     // the GPU (not where the streams' addresses are only known on the device)
+    if (fused && !takes_ring(ctx, n_pages)) return fail(ctx, PQ2_DEVICE_ERROR, "internal: fused lookup outside ring_kernel");
     const bool scout = !front && (ctx->mode == pq2_ctx::kScout || (ctx->mode == pq2_ctx::kAuto && n_pages < kScoutMaxPages));
     const bool ring = !scout && (ctx->mode == pq2_ctx::kRing || (ctx->mode == pq2_ctx::kAuto && n_pages >= kFusedMinPages));
+    // (kScoutMaxPages >= kFusedMinPages: in kAuto a batch is either walked by the scout kernels or takes ring_kernel)
     const bool per_page = ring || ctx->mode == pq2_ctx::kPerPage;
     // tiles are numbered round-major: all tiles of round 0 of all pages, then round 1, ...
     const bool split = !per_page && !scout && tiles >= ctx->min_rounded_tiles;
@@ -474,7 +493,13 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
             if ((st = reserve(ctx, ctx->d_tickets, ticket_bytes))) return st;
             PQ2_HIP(ctx, hipMemsetAsync(ctx->d_tickets.ptr, 0, ticket_bytes, stream));
         }
+        if (fused)  // the walking wave and the expanding waves merge what they report: from 0
+            PQ2_HIP(ctx, hipMemsetAsync(d_status, 0, n_pages * sizeof(int32_t), stream));
         if ((st = stamped(true, stream, [&] {
+                 if (fused)
+                     return pq2_launch_ring_dict(d_pages, static_cast<uint32_t>(n_pages), d_status,
+                                                 static_cast<uint32_t *>(ctx->d_tickets.ptr), d_tile_mask, fused->d_dicts,
+                                                 fused->value_words, fused->max_dict_bytes, stream);
                  if (ring)
                      return pq2_launch_ring(d_pages, static_cast<uint32_t>(n_pages), d_status,
                                             static_cast<uint32_t *>(ctx->d_tickets.ptr), max_bits, d_tile_mask, stream);
@@ -529,7 +554,7 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
     ctx->last_n_pages = n_pages;
     ctx->last_scout = scout;
     ctx->last_scout_tiles = stiles;
-    ctx->last_schedule = ring ? "ring_kernel" : per_page ? "decode_kernel" : scout ? "scout+expand_kernel" : "expand_kernel";
+    ctx->last_schedule = fused ? "ring_kernel+dictionary" : ring ? "ring_kernel" : per_page ? "decode_kernel" : scout ? "scout+expand_kernel" : "expand_kernel";
     return PQ2_OK;
 }
 
@@ -707,31 +732,56 @@ int32_t pq2_decode_dict_batch_device(pq2_ctx *ctx, const void *d_in, uint64_t in
     }
     int32_t st;
     if (ctx->busy && ctx->last_stream != stream) PQ2_HIP(ctx, hipStreamSynchronize(ctx->last_stream));
-    if ((st = reserve(ctx, ctx->d_indices, std::max<uint64_t>(out_values, 1) * sizeof(uint32_t)))) return st;
-    uint32_t *d_idx = static_cast<uint32_t *>(ctx->d_indices.ptr);
-    if ((st = enqueue_batch(ctx, d_in, in_bytes, descs, n_pages, d_idx, out_values, stream))) return st;
+    // Batches that ring_kernel takes, of pages narrow enough and with dictionaries small enough to lie in LDS beside
+    // the ring, are looked up where they are decoded; everything else is decoded into a buffer of indices first
+    // and looked up by a second kernel.  (PQ2_FUSED_GATHER=0: always the latter.)
+    uint64_t max_dict_bytes = 0;
+    uint32_t max_bits = 0;
+    for (uint64_t i = 0; i < n_pages; ++i) {
+        max_dict_bytes = std::max<uint64_t>(max_dict_bytes, uint64_t(dicts[i].dict_len) * value_size);
+        if (descs[i].num_bits <= 32 && descs[i].num_values > 0) max_bits = std::max(max_bits, descs[i].num_bits);
+    }
+    static const bool fused_allowed = [] {
+        const char *v = std::getenv("PQ2_FUSED_GATHER");
+        return !(v && std::atoi(v) == 0);
+    }();
+    const bool fuse = fused_allowed && n_pages > 0 && takes_ring(ctx, n_pages) && max_bits <= pq2_ring_dict_max_bits() &&
+                      max_dict_bytes <= pq2_ring_dict_max_bytes();
+    uint32_t *d_idx = nullptr;
+    if (!fuse) {
+        if ((st = reserve(ctx, ctx->d_indices, std::max<uint64_t>(out_values, 1) * sizeof(uint32_t)))) return st;
+        d_idx = static_cast<uint32_t *>(ctx->d_indices.ptr);
+        if ((st = enqueue_batch(ctx, d_in, in_bytes, descs, n_pages, d_idx, out_values, stream))) return st;
+    }
     if (n_pages > 0) {
         const size_t bytes = n_pages * sizeof(GatherPage);
         if ((st = stage_block(ctx, bytes, bytes))) return st;
         GatherPage *g = static_cast<GatherPage *>(ctx->h_gather);
-        uint64_t tiles = 0, max_dict_bytes = 0;
+        uint64_t tiles = 0;
         const uint64_t kGatherTileValues = pq2_gather_tile_values();
         for (uint64_t i = 0; i < n_pages; ++i) {
             const pq2_page_desc &d = descs[i];
-            max_dict_bytes = std::max<uint64_t>(max_dict_bytes, uint64_t(dicts[i].dict_len) * value_size);
             g[i].idx_addr = reinterpret_cast<uint64_t>(d_idx) + d.out_off * sizeof(uint32_t);
             g[i].out_addr = reinterpret_cast<uint64_t>(d_out) + d.out_off * value_size;
             g[i].dict_addr = reinterpret_cast<uint64_t>(d_dict) + dicts[i].dict_off;
             g[i].dict_len = dicts[i].dict_len;
-            g[i].num_values = ctx->host_status[i] == PQ2_OK ? static_cast<uint32_t>(d.num_values) : 0u;
+            g[i].num_values = (fuse ? d.num_bits <= 32 : ctx->host_status[i] == PQ2_OK) ? static_cast<uint32_t>(d.num_values) : 0u;
             g[i].first_tile = static_cast<uint32_t>(tiles);
             g[i].reserved = 0;
             tiles += (uint64_t(g[i].num_values) + kGatherTileValues - 1) / kGatherTileValues;
         }
         if ((st = upload_block(ctx, bytes, stream))) return st;
-        PQ2_HIP(ctx, pq2_launch_gather(ctx->d_gather.ptr, static_cast<uint32_t>(n_pages), static_cast<uint32_t>(tiles),
-                                       value_size / 4, max_dict_bytes, static_cast<int32_t *>(ctx->d_status.ptr),
-                                       stream));
+        if (fuse) {
+            // (the descriptors' output offsets are checked against the values; the kernel writes through `dicts`)
+            const FusedDict fd{ctx->d_gather.ptr, value_size / 4, static_cast<uint32_t>(max_dict_bytes)};
+            if ((st = enqueue_batch(ctx, d_in, in_bytes, descs, n_pages, static_cast<uint32_t *>(d_out), out_values, stream,
+                                    nullptr, 0, nullptr, &fd)))
+                return st;
+        } else {
+            PQ2_HIP(ctx, pq2_launch_gather(ctx->d_gather.ptr, static_cast<uint32_t>(n_pages), static_cast<uint32_t>(tiles),
+                                           value_size / 4, max_dict_bytes, static_cast<int32_t *>(ctx->d_status.ptr),
+                                           stream));
+        }
     }
     if (status) return fetch_status(ctx, status, n_pages);
     return PQ2_OK;

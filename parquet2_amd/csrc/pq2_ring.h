@@ -1,0 +1,1276 @@
+// ring_kernel: one workgroup per page, the stream read from memory exactly once (gfx950 / MI355X).
+//
+// decode_kernel (pq2_kernels.hip) has the wave that walks a page's run headers and the three waves that expand its
+// tiles meet through global memory: the walk loads the stream, lists header positions and block starts in device
+// arrays, and the expanding waves load those lists and the stream a second time.  Here everything the four waves
+// hand to each other stays in the workgroup's LDS:
+//
+//   ring   the page's stream bytes, a-offset `a` at ring[a mod R] (R = 32 KiB, or 64 KiB for pages wider than 16
+//          bits).  The walking wave fills it in slots of 4 KiB straight from memory (buffer loads with an LDS
+//          destination: no registers, no second copy), chases the headers inside it, and the expanding waves take
+//          headers and bit-packed fields out of it.  64 bytes behind its end mirror its first 64, so that a read of
+//          a few dwords never has to wrap.
+//   hq     the header-position queue: a-offset of the header of every run that yields values, run i at hq[i mod 512].
+//   rq     the block-start queue: the Resume entry of 1024-value block b at rq[b mod 64].
+//   ctl    the hand-off words: what the walk has published (values covered, runs listed, bytes landed), and for
+//          every expanding wave the tile it holds and the lowest stream byte it still needs.
+//
+// Flow control replaces the tile lead of decode_kernel: the walk overwrites ring bytes, hq and rq entries only
+// once no expanding wave needs them (the lowest needed byte / the lowest held tile), and it says so when it has to
+// wait for room, so that the expanding waves go on with whatever is published instead of waiting for a whole span.
+// Every wait is bounded; a wait that runs out marks the page PQ2_DEVICE_ERROR and ends all four waves.
+#pragma once
+#include <stdlib.h>
+
+#include "pq2_device.h"
+
+namespace pq2 {
+
+constexpr uint32_t kSlot = 4096;                // bytes per ring fill
+constexpr uint32_t kMirror = 64;                // bytes behind the ring that repeat its first bytes
+#ifndef PQ2_RING_EXPANDERS
+#define PQ2_RING_EXPANDERS 3
+#endif
+constexpr uint32_t kRingExpanders = PQ2_RING_EXPANDERS;  // 3 or 4 expanding waves beside the walking one
+constexpr uint32_t kRingThreads = 64u * (kRingExpanders + 1u);
+// the queues share the compute unit's LDS with the ring: four workgroups of 40 KiB each
+constexpr uint32_t kHq = kRingExpanders == 3 ? 512 : 256;  // entries of the header-position queue
+constexpr uint32_t kRq = kRingExpanders == 3 ? 64 : 32;    // entries of the block-start queue
+#ifndef PQ2_RING_SLOTS_IN_FLIGHT
+#define PQ2_RING_SLOTS_IN_FLIGHT 4
+#endif
+constexpr uint32_t kSlotsInFlight = PQ2_RING_SLOTS_IN_FLIGHT;  // ring fills the walk keeps in flight
+constexpr uint32_t kPassRuns = 64;  // runs the walk parks before it places and publishes them (one lane each)
+#ifndef PQ2_RING_PASS_BYTES
+#define PQ2_RING_PASS_BYTES 0xffffffffu
+#endif
+// ... or once the parked runs span this many stream bytes: what is parked is not published, so nobody can take
+// it out of the ring yet
+constexpr uint32_t kPassBytes = PQ2_RING_PASS_BYTES;
+#ifndef PQ2_RING_WALK_PRIO
+#define PQ2_RING_WALK_PRIO 2
+#endif
+constexpr uint32_t kNotYet = 0xfffffffeu;       // header position of a run the walk has not published yet
+constexpr uint32_t kTileFresh = 0xffffffffu;    // "lowest byte needed" of a wave that has not looked at its tile yet
+constexpr uint32_t kNoNeed = 0xffffffc0u;       // ... of a wave that needs no stream byte any more
+constexpr uint32_t kRingMaxPolls = 1u << 22;    // of >= 0.1 us each: far beyond any wait of a healthy page
+
+#ifndef PQ2_RING_TILE_BLOCKS
+#define PQ2_RING_TILE_BLOCKS 4
+#endif
+// What an expanding wave takes at a time: a tile of this many 1024-value blocks (smaller than the tiles of the
+// other kernels if that pays: the bytes of the tiles in progress are what keeps the ring occupied).
+constexpr uint32_t kRingTileBlocks = PQ2_RING_TILE_BLOCKS;  // 2 or 4
+constexpr uint32_t kRingTileValues = kRingTileBlocks * kBlockValues;
+constexpr uint32_t kRingTableRuns = 64;                      // run-table entries per expanding wave
+constexpr uint32_t kRingSpanBlocks = 2;                      // blocks per span
+constexpr uint32_t kRingSpanValues = kRingSpanBlocks * kBlockValues;
+constexpr uint32_t kRingSpanChunks = kRingSpanValues / 4u;   // 16-byte output chunks per span
+constexpr uint32_t kRingChunkSlots = kRingSpanChunks + 8u;   // + 2 when the output is not 16-byte aligned, rounded up
+constexpr uint32_t kRingNoRun = 0xffffffffu;
+#ifndef PQ2_RING_STEP_GROUP
+#define PQ2_RING_STEP_GROUP 5
+#endif
+constexpr uint32_t kRingStepGroup = PQ2_RING_STEP_GROUP;  // emission steps whose LDS reads are in flight together
+
+struct RingCtl {
+    uint32_t covered;    // values covered by the published entries (kAllParsed: the page's entries are complete)
+    uint32_t runs;       // hq entries published
+    uint32_t floor;      // every run published from now on has its header at or behind this a-offset
+    uint32_t landed;     // the ring holds the stream up to this a-offset
+    uint32_t final_hi;   // the ring will never hold more than this
+    uint32_t blocked;    // the walk waits for room
+    uint32_t abort;      // a wait ran out: everybody leaves
+    uint32_t next_tile;  // the next tile to hand out
+    uint64_t expander[4];  // per expanding wave: tile it holds << 32 | lowest a-offset it still needs
+    uint32_t pick[8];      // pick_walker's scratch
+};
+constexpr uint32_t kRingAllParsed = 0xffffffffu;
+
+#ifdef PQ2_RING_TIMING  // diagnostic build: shader clocks spent per role and wait, summed over all waves
+// 0 walk total, 1 walk waiting for room, 2 walk waiting for fills, 3 walk chase, 4 walk after its last publish,
+// 8 expand total, 9 waiting for a block start, 10 waiting for runs, 11 waiting for bytes
+__device__ unsigned long long g_ring_clocks[32];  // 16..: event counts of the walk (see PQ2_COUNT uses)
+#define PQ2_CLOCK() __builtin_amdgcn_s_memtime()
+#define PQ2_CLOCK_ADD(SLOT, T0) clocks[(SLOT) & 7] += __builtin_amdgcn_s_memtime() - (T0)
+#define PQ2_COUNT(SLOT, V) counts[SLOT] += (V)
+#define PQ2_CLOCK_FLUSH(BASE)                                                                            \
+    do {                                                                                                 \
+        if (lane == 0)                                                                                   \
+            for (int i_ = 0; i_ < 8; ++i_)                                                               \
+                if (clocks[i_]) atomicAdd(&g_ring_clocks[(BASE) + i_], (unsigned long long)clocks[i_]);  \
+    } while (0)
+#else
+#define PQ2_CLOCK() 0ull
+#define PQ2_CLOCK_ADD(SLOT, T0) do { (void)(T0); } while (0)
+#define PQ2_CLOCK_FLUSH(BASE) do { } while (0)
+#define PQ2_COUNT(SLOT, V) do { } while (0)
+#endif
+
+// LDS bytes of one workgroup for a ring of `ring_bytes`
+__host__ __device__ constexpr uint32_t ring_lds_bytes(uint32_t ring_bytes) {
+    return ring_bytes + kMirror + kHq * 4u + kRq * 16u + (uint32_t)sizeof(RingCtl) +
+           kRingExpanders * ((kRingTableRuns + 2u) * 8u + kRingChunkSlots * 2u);
+}
+
+__device__ __forceinline__ uint32_t lds_load(const uint32_t *p) {
+    return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+}
+__device__ __forceinline__ void lds_store(uint32_t *p, uint32_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// What this wave has written to LDS is in place before what it writes next (LDS operations of a wave execute in
+// order; the wait also covers the hand-off words themselves).
+__device__ __forceinline__ void lds_release() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// Keeps the compiler from reading LDS ahead of a hand-off word it has just looked at.
+__device__ __forceinline__ void lds_acquire() { asm volatile("" ::: "memory"); }
+
+// ---------------------------------------------------------------------------
+// The walking wave
+// ---------------------------------------------------------------------------
+struct RingShared {
+    uint8_t *ring;
+    uint32_t ring_bytes;  // R, a power of two
+    uint32_t *hq;
+    Resume *rq;
+    RingCtl *ctl;
+};
+
+// kMerge: the page's status is shared with the expanding waves (a dictionary index out of range): the larger
+// status stays.
+template <bool kWide, bool kMerge>
+__device__ __forceinline__ void ring_walk(const PageDev &pg, const uint32_t page, const RingShared sh,
+                                          int32_t *__restrict__ status, const uint32_t lane) {
+    auto set_status = [&](int32_t st) {
+        if (lane == 0) {
+            if (kMerge)
+                atomicMax(&status[page], st);
+            else
+                status[page] = st;
+        }
+    };
+    RingCtl *const ctl = sh.ctl;
+#ifdef PQ2_RING_TIMING
+    uint64_t clocks[8] = {};
+    uint64_t counts[12] = {};
+#endif
+    const uint64_t clock_begin = PQ2_CLOCK();
+    const uint32_t n = pg.num_values;  // > 0
+    const uint32_t w = pg.num_bits;
+    const uint32_t n_blocks = (n + kBlockValues - 1u) / kBlockValues;
+    const uint32_t n_tiles = (n + kRingTileValues - 1u) / kRingTileValues;
+    const uint32_t R = sh.ring_bytes, rmask = R - 1u;
+    const uint32_t delta = (uint32_t)(pg.in_addr & 15u);
+    const uint32_t end = delta + pg.in_len;  // a-offset one past the last stream byte
+    const uint32_t rb = ceil8(w);
+    const uint32_t rb_mask = rb < 4 ? (1u << (rb * 8u)) - 1u : ~0u;
+    const uint32_t ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)sh.ring;
+
+    uint32_t n_runs = 0;       // hq entries written
+    uint32_t produced = 0;     // values the listed runs yield
+    uint32_t blocks_done = 0;  // Resume entries of blocks [0, blocks_done) are written
+    uint32_t issued_hi = 0, landed_hi = 0;  // ring fills requested / arrived, in a-offsets (multiples of kSlot)
+    uint32_t final_hi = 0;     // nothing behind this a-offset is ever loaded
+    bool aborted = false;
+#ifdef PQ2_RING_DEBUG
+    uint32_t dbg_site = 0;
+#define PQ2_SITE(N) dbg_site = N
+#else
+#define PQ2_SITE(N)
+#endif
+    uint32_t keep = delta;     // header of the first run that is not placed yet: the bytes from there on stay in the ring
+
+    // ---- what the expanding waves still need ----------------------------------------------------------------
+    // low_byte: no stream byte below it is needed any more; low_tile: no block below 4 * low_tile is.
+    auto limits = [&](uint32_t &low_byte, uint32_t &low_tile) {
+        low_byte = 0xffffffffu;
+        low_tile = 0xffffffffu;
+#pragma unroll
+        for (uint32_t e = 0; e < kRingExpanders; ++e) {
+            const uint64_t x = __hip_atomic_load(&ctl->expander[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t tile = __builtin_amdgcn_readfirstlane((uint32_t)(x >> 32));
+            uint32_t byte = __builtin_amdgcn_readfirstlane((uint32_t)x);
+            if (tile >= n_tiles) continue;  // that wave is through
+            low_tile = min(low_tile, tile);
+            if (byte == kTileFresh) {
+                // it has not read its tile's first Resume entry yet: the entry says what it will ask for
+                if (tile * kRingTileBlocks >= blocks_done) continue;  // not even written: nothing below the walk
+                const Resume r = sh.rq[(tile * kRingTileBlocks) & (kRq - 1u)];
+                const uint32_t rem_kind = __builtin_amdgcn_readfirstlane(r.rem_kind);
+                const uint32_t payload = __builtin_amdgcn_readfirstlane(r.payload);
+                const uint32_t skip = __builtin_amdgcn_readfirstlane(r.skip);
+                byte = (rem_kind >> 31) == kBitpacked ? payload + (skip >> 3) * w : skip;
+            }
+            low_byte = min(low_byte, byte);
+        }
+    };
+    // What limits() said last, lowered wherever the truth may since have dropped below it: the needs of the expanding
+    // waves only rise, except that a wave whose tile had no entry yet (no need) gets one when the walk publishes
+    // the tile -- never below the first byte published then (`keep` at that time).  The checks on the walk's way
+    // look at these and ask again only when they fail.
+    uint32_t known_byte = 0, known_tile = 0;
+    auto refresh = [&]() { limits(known_byte, known_tile); };
+    auto abort_all = [&]() {
+#ifdef PQ2_RING_DEBUG
+        if (lane == 0 && lds_load(&ctl->abort) == 0u) status[page] = 100 + (int32_t)dbg_site;
+#else
+        set_status(6);  // PQ2_DEVICE_ERROR
+#endif
+        lds_store(&ctl->abort, 1u);
+        aborted = true;
+    };
+    // ---- ring fills ------------------------------------------------------------------------------------------
+    // The four loads of a fill are written in assembly so that the compiler does not know of them: it would wait for
+    // every load in flight in front of each LDS store of the walk (it cannot tell that they go elsewhere), and the
+    // fills are meant to stay in flight while the walk goes on.  land() waits for them by count.
+    // M0: LDS address of the destination; lane l's 16 bytes land at M0 + 16 l.
+    const u32x4 rsrc_words = {(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(pg.in_addr - delta)),
+                              (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)((pg.in_addr - delta) >> 32) & 0xffffu),
+                              (uint32_t)__builtin_amdgcn_readfirstlane((end + 3u) & ~3u), 0x00020000u};
+    auto issue_slot = [&]() {
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(ring_lds + (issued_hi & rmask));
+        const uint32_t off0 = issued_hi + lane * 16u, off1 = off0 + 1024u, off2 = off0 + 2048u, off3 = off0 + 3072u;
+        uint32_t m0_was;
+        asm volatile(
+            "s_mov_b32 %[m0_was], m0\n\t"
+            "s_mov_b32 m0, %[dst]\n\t"
+            "s_nop 0\n\t"
+            "buffer_load_dwordx4 %[off0], %[rsrc], 0 offen lds\n\t"
+            "s_add_u32 m0, m0, 0x400\n\t"
+            "s_nop 0\n\t"
+            "buffer_load_dwordx4 %[off1], %[rsrc], 0 offen lds\n\t"
+            "s_add_u32 m0, m0, 0x400\n\t"
+            "s_nop 0\n\t"
+            "buffer_load_dwordx4 %[off2], %[rsrc], 0 offen lds\n\t"
+            "s_add_u32 m0, m0, 0x400\n\t"
+            "s_nop 0\n\t"
+            "buffer_load_dwordx4 %[off3], %[rsrc], 0 offen lds\n\t"
+            "s_mov_b32 m0, %[m0_was]"
+            : [m0_was] "=&s"(m0_was)
+            : [dst] "s"(dst), [rsrc] "s"(rsrc_words), [off0] "v"(off0), [off1] "v"(off1), [off2] "v"(off2),
+              [off3] "v"(off3)
+            : "memory", "scc");
+        issued_hi += kSlot;
+    };
+    // may the slot at issued_hi be filled, if nothing below `low` is needed?  (it replaces bytes [issued_hi - R, ...))
+    auto room_for_slot = [&](uint32_t low) { return (uint64_t)issued_hi + kSlot <= (uint64_t)(low & ~63u) + R; };
+    // Requests ring fills as far as there is room and the in-flight limit allows.  `ask`: when the room known so far
+    // does not do, look again at what the expanding waves need (a handful of LDS round trips: only where a fill is
+    // needed now, not for the ones requested ahead).
+    auto top_up = [&](uint32_t keep_from, bool ask) {
+        while (issued_hi < final_hi && issued_hi - landed_hi < kSlotsInFlight * kSlot) {
+            if (!room_for_slot(min(known_byte, keep_from))) {
+                if (!ask) break;
+                refresh();
+                ask = false;
+                PQ2_COUNT(2, 1);  // looks at the limits because a fill was needed
+                if (!room_for_slot(min(known_byte, keep_from))) {
+                    PQ2_COUNT(3, 1);  // ... in vain
+                    break;
+                }
+            }
+            issue_slot();
+        }
+    };
+    // Waits for the oldest fill in flight (the memory operations of a wave complete in order, so that is "all but
+    // the instructions of the fills requested after it") and says that its bytes are there.
+    auto land = [&]() {
+        PQ2_COUNT(1, 1);  // fills waited for
+        const uint64_t clock_land = PQ2_CLOCK();
+        static_assert(kSlot / 1024u == 4u && kSlotsInFlight <= 4u, "the waits below spell out four loads per fill");
+        const uint32_t behind = (issued_hi - landed_hi) / kSlot - 1u;  // fills requested after the oldest one
+        if (behind == 0u)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (behind == 1u)
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (behind == 2u)
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        PQ2_CLOCK_ADD(2, clock_land);
+        if ((landed_hi & rmask) == 0u) {  // the ring's first bytes once more behind its end
+            if (lane < kMirror / 4u) ((uint32_t *)(sh.ring + R))[lane] = ((const uint32_t *)sh.ring)[lane];
+            lds_release();
+        }
+        landed_hi += kSlot;
+        lds_store(&ctl->landed, landed_hi);
+    };
+    // Waits until `ready(low_byte, low_tile)`; tells the expanding waves that the walk stands still meanwhile.
+    auto wait_room = [&](auto ready) {
+        if (ready(known_byte, known_tile)) return;
+        bool told = false;
+        const uint64_t clock_wait = PQ2_CLOCK();
+        for (uint32_t polls = 0;; ++polls) {
+            refresh();
+            if (ready(known_byte, known_tile)) break;
+            if (!told) {
+                lds_store(&ctl->blocked, 1u);
+                told = true;
+            }
+            if (polls == kRingMaxPolls || lds_load(&ctl->abort) != 0u) {
+                abort_all();
+                break;
+            }
+            // The ring is kept as full as the room allows meanwhile: an expanding wave may be waiting for the
+            // bytes of a run that is published already, and it is that wave's progress that makes the room.
+            top_up(keep, false);  // (refreshed above)
+            if (issued_hi != landed_hi) land();
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (told) lds_store(&ctl->blocked, 0u);
+        PQ2_CLOCK_ADD(1, clock_wait);
+    };
+
+    // Makes stream bytes [at, at + bytes) resident as far as that takes no waiting for the expanding waves
+    // (`at` and everything behind it stay in the ring); false: there is no room yet.
+    auto try_ensure = [&](uint32_t at, uint32_t bytes) -> bool {
+        const uint32_t want = min(at + bytes, final_hi);
+        while (landed_hi < want) {
+            if (issued_hi == landed_hi) {
+                PQ2_COUNT(4, 1);  // bytes needed with no fill in flight
+                top_up(keep, true);
+                if (issued_hi == landed_hi) return false;
+            }
+            land();
+            top_up(keep, false);  // the next fills are on their way while the walk works through these
+        }
+        return true;
+    };
+    // the same, waiting for room; only when everything the walk knows has been published
+    auto ensure = [&](uint32_t at, uint32_t bytes) {
+        PQ2_SITE(3);
+        // (the wait itself keeps the ring fed: what it is waiting for may have landed before there is room for
+        // yet another slot)
+        while (!aborted && !try_ensure(at, bytes))
+            wait_room([&](uint32_t low_byte, uint32_t) {
+                return landed_hi >= min(at + bytes, final_hi) || room_for_slot(min(low_byte, keep));
+            });
+    };
+
+    // ---- publishing ------------------------------------------------------------------------------------------
+    // runs first, floor second: a reader that takes the floor first and the run count second knows that every
+    // run from that count on starts at or behind that floor
+    auto publish = [&](uint32_t covered, uint32_t floor_pos) {
+        known_byte = min(known_byte, keep);  // what becomes visible now lies behind `keep`, and so will its takers' needs
+        lds_release();
+        lds_store(&ctl->runs, n_runs);
+        lds_store(&ctl->floor, floor_pos);
+        lds_store(&ctl->covered, covered);
+    };
+    // hq entries [n_runs, n_runs + count) may be written once the entries they replace are not needed: those lie
+    // below every byte an expanding wave still needs
+    auto hq_room = [&](uint32_t count) {
+        if (count == 0u || n_runs + count <= kHq) return;
+        const uint32_t newest_replaced = __builtin_amdgcn_readfirstlane(sh.hq[(n_runs + count - 1u) & (kHq - 1u)]);
+        PQ2_SITE(1);
+        wait_room([&](uint32_t low_byte, uint32_t) { return newest_replaced < low_byte; });
+    };
+    // Writes the Resume entries of blocks [from, to) as make(b) gives them, as far ahead of the lowest held tile as
+    // the queue allows, publishing as it goes.
+    auto emit_blocks = [&](uint32_t from, uint32_t to, uint32_t floor_pos, auto make) {
+        uint32_t b = from;
+        while (b < to && !aborted) {
+            uint32_t allowed = b;
+            PQ2_SITE(2);
+            wait_room([&](uint32_t, uint32_t low_tile) {
+                allowed = low_tile == 0xffffffffu ? to : min(to, low_tile * kRingTileBlocks + kRq);
+                return allowed > b;
+            });
+            if (aborted) break;
+            for (uint32_t bb = b + lane; bb < allowed; bb += 64u) sh.rq[bb & (kRq - 1u)] = make(bb);
+            b = allowed;
+            blocks_done = b;
+            if (b < to) publish(min(b * kBlockValues, n), floor_pos);
+        }
+    };
+    // the page's entries are complete: closes the header list, the blocks behind the last value the stream holds
+    // read zeros (mod.rs:95)
+    auto finish = [&](int32_t st, uint32_t floor_pos) {
+        hq_room(1u);
+        if (!aborted) {
+            if (lane == 0) sh.hq[n_runs & (kHq - 1u)] = kEndPos;
+            ++n_runs;
+            const uint32_t listed = n_runs - 1u;
+            emit_blocks((produced + kBlockValues - 1u) / kBlockValues, n_blocks, floor_pos, [&](uint32_t) {
+                Resume e;
+                e.run_index = listed;
+                e.rem_kind = kRemMask | (kRle << 31);
+                e.payload = 0;
+                e.skip = kEndPos;
+                return e;
+            });
+        }
+        if (aborted || lds_load(&ctl->abort) != 0u) return;
+        set_status(st);
+        // nothing behind the walk's position is needed: the fills end there
+        final_hi = min(final_hi, (floor_pos + 64u + kSlot - 1u) & ~(kSlot - 1u));
+        lds_store(&ctl->final_hi, final_hi);
+        publish(kRingAllParsed, floor_pos);
+    };
+
+    if (w == 0 || pg.in_len == 0 || w > 32) {  // decoder.rs:31-37: nothing to iterate
+        finish(0, 0u);
+        return;
+    }
+    final_hi = (end + 64u + kSlot - 1u) & ~(kSlot - 1u);  // reads of a few dwords behind the last byte stay inside
+    lds_store(&ctl->final_hi, final_hi);
+
+    uint32_t pos = delta;  // a-offset of the next header
+    for (;;) {
+        keep = pos;  // everything before is placed and published: the waves that expand it say what they need
+        const uint64_t clock_top = PQ2_CLOCK();
+        refresh();  // once per pass
+        PQ2_COUNT(5, 1);                                   // passes
+        PQ2_COUNT(6, keep - min(known_byte, keep));        // bytes between the lowest need and the first unplaced run
+        PQ2_COUNT(7, landed_hi - min(landed_hi, keep));    // bytes landed ahead of the walk
+        PQ2_COUNT(8, issued_hi - landed_hi);               // bytes in flight
+        top_up(keep, false);
+        PQ2_COUNT(9, issued_hi - landed_hi);               // ... after topping up
+        ensure(pos, 32u);
+        PQ2_CLOCK_ADD(6, clock_top);
+        if (aborted) return;
+        // ---- chase: park up to 64 runs, record i in lane i (see PQ2_CHASE) ---------------------------------
+        uint32_t r_pos = 0, r_lo = 0, r_hi = 0, r_info = 0;
+        uint32_t m = 0;     // parked records
+        uint32_t term = 0;  // kEnd / kPanic once the chase cannot go on
+        for (;;) {
+            uint32_t lo, hi, groups, t, bytes, nm1, chk, addr;
+            uint64_t exec_all;
+            uint32_t m0_kept;
+            const uint32_t voff = ring_lds - (pos & ~rmask);  // this turn of the ring, as if it were the whole stream
+            // stops at the end of the stream, of the bytes that have landed, and of this turn of the ring (the
+            // mirror holds the 8 bytes of a header that begins in the ring's last bytes)
+            const uint32_t chase_limit = __builtin_amdgcn_readfirstlane(min(min(end - 1u, landed_hi - 9u), pos | rmask));
+            PQ2_COUNT(0, 1);  // entries into the chase loop
+            const uint64_t clock_chase = PQ2_CLOCK();
+            if constexpr (kWide) {
+                PQ2_CHASE("v_readfirstlane_b32 %[hi], v3\n\t", "v_writelane_b32 %[r_hi], %[hi], m0\n\t")
+            } else {
+                PQ2_CHASE("", "")
+            }
+            PQ2_CLOCK_ADD(3, clock_chase);
+            if ((~lo & kExplicit) == 0u || nm1 > end - 1u) {
+                // three or more header bytes, a run cut by the end of the stream, or the end itself: the record
+                // parked last does not count
+                --m;
+                pos = __builtin_amdgcn_readlane(r_pos, m);
+                if (!try_ensure(pos, 32u)) break;  // place what is parked, then wait for room
+                auto rd = [&](uint32_t a) -> uint32_t {
+                    return __builtin_amdgcn_readfirstlane(*(const uint32_t *)&sh.ring[a & rmask]);
+                };
+                const RunInfo run = decode_run(rd, pos, end, w, 0xffffffffu);
+                const uint32_t e_lo = kExplicit | (run.kind << 16) | (((run.next - pos) & 0xffu) << 20);
+                const uint32_t e_hi = __builtin_amdgcn_readfirstlane(run.count);
+                const uint32_t e_info = __builtin_amdgcn_readfirstlane(run.kind == kRle ? run.value : run.payload);
+                uint32_t m0_was;
+                asm volatile(
+                    "s_mov_b32 %[m0_was], m0\n\t"
+                    "s_mov_b32 m0, %[m]\n\t"
+                    "v_writelane_b32 %[r_pos], %[pos], m0\n\t"
+                    "v_writelane_b32 %[r_lo], %[e_lo], m0\n\t"
+                    "v_writelane_b32 %[r_hi], %[e_hi], m0\n\t"
+                    "v_writelane_b32 %[r_info], %[e_info], m0\n\t"
+                    "s_mov_b32 m0, %[m0_was]"
+                    : [r_pos] "+v"(r_pos), [r_lo] "+v"(r_lo), [r_hi] "+v"(r_hi), [r_info] "+v"(r_info),
+                      [m0_was] "=&s"(m0_was)
+                    : [m] "s"(m), [pos] "s"(pos), [e_lo] "s"(e_lo), [e_hi] "s"(e_hi), [e_info] "s"(e_info));
+                ++m;
+                if (run.kind >= kEnd) {
+                    term = run.kind;
+                    break;
+                }
+                pos = run.next;
+            }
+            if (m == kPassRuns || pos - keep >= kPassBytes) break;
+            const uint64_t clock_more = PQ2_CLOCK();
+            const bool more = try_ensure(pos, 9u);
+            PQ2_CLOCK_ADD(7, clock_more);
+            if (!more) break;
+        }
+        const uint64_t clock_place = PQ2_CLOCK();
+
+        // ---- place: lane i decodes record i; a prefix sum over the run lengths places the runs -------------
+        const ParkedRun parked = decode_parked(r_pos, r_lo, r_hi, r_info, rb, rb_mask);
+        const uint32_t kind = parked.kind, info = parked.info, after = parked.after;
+        const uint32_t left = n - produced;  // > 0
+        const uint32_t cnt = (lane < m && kind < kEnd) ? min(parked.count, left) : 0u;
+        const uint32_t incl = wave_inclusive_sum_saturating(cnt, left);
+        const uint32_t before = __builtin_amdgcn_update_dpp(0u, incl, 0x138, 0xf, 0xf, false);  // wave_shr:1
+        const uint32_t eff = min(cnt, left - before);  // the page ends inside or before this run: mod.rs:76-78
+        const bool yields = eff > 0u;
+        const uint64_t ymask = __ballot(yields);
+        const uint32_t n_yield = (uint32_t)__popcll(ymask);
+        const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+        hq_room(n_yield);
+        if (aborted) return;
+        const uint32_t idx =
+            n_runs + __builtin_amdgcn_mbcnt_hi((uint32_t)(ymask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ymask, 0u));
+        if (yields) sh.hq[idx & (kHq - 1u)] = r_pos;
+        n_runs += n_yield;
+        // the run holds values [first, first + eff) of the page: it starts blocks b_first..b_last (if any)
+        const uint32_t first = produced + before;
+        const uint32_t b_first = (first + kBlockValues - 1u) / kBlockValues;
+        const uint32_t b_last = (first + eff - 1u) / kBlockValues;  // meaningful where `yields`
+        const bool starts = yields && b_last >= b_first;
+        if (total != 0u) {
+            const uint32_t pass_last = (produced + total - 1u) / kBlockValues;  // the last block these runs start
+            // in rounds, as far ahead of the lowest held tile as the block-start queue allows (one round nearly always)
+            while (blocks_done <= pass_last && !aborted) {
+                uint32_t allowed = blocks_done;
+                PQ2_SITE(4);
+                wait_room([&](uint32_t, uint32_t low_tile) {
+                    allowed = low_tile == 0xffffffffu ? pass_last + 1u : min(pass_last + 1u, low_tile * kRingTileBlocks + kRq);
+                    return allowed > blocks_done;
+                });
+                if (aborted) return;
+                const uint32_t r_first = max(b_first, blocks_done), r_last = min(b_last, allowed - 1u);
+                const uint32_t nb = (starts && r_last >= r_first) ? r_last - r_first + 1u : 0u;
+                auto write_entries = [&](uint32_t b_from, uint32_t b_step, uint32_t b_to, uint32_t run_index,
+                                         uint32_t run_first, uint32_t run_eff, uint32_t run_kind, uint32_t run_info,
+                                         uint32_t run_after) {
+                    for (uint32_t b = b_from; b <= b_to; b += b_step) {
+                        const uint32_t skip = b * kBlockValues - run_first;
+                        Resume e;
+                        e.run_index = run_index;
+                        e.rem_kind = (run_eff - skip) | (run_kind << 31);
+                        e.payload = run_info;
+                        e.skip = run_kind == kRle ? run_after : skip;
+                        sh.rq[b & (kRq - 1u)] = e;
+                    }
+                };
+                if (nb != 0u && nb <= 4u) write_entries(r_first, 1u, r_last, idx, first, eff, kind, info, after);
+                for (uint64_t big = __ballot(nb > 4u); big != 0; big &= big - 1) {  // long runs: the whole wave writes
+                    const uint32_t l = (uint32_t)__builtin_ctzll(big);
+                    write_entries(__builtin_amdgcn_readlane(r_first, l) + lane, 64u, __builtin_amdgcn_readlane(r_last, l),
+                                  __builtin_amdgcn_readlane(idx, l), __builtin_amdgcn_readlane(first, l),
+                                  __builtin_amdgcn_readlane(eff, l), __builtin_amdgcn_readlane(kind, l),
+                                  __builtin_amdgcn_readlane(info, l), __builtin_amdgcn_readlane(after, l));
+                }
+                blocks_done = allowed;
+                if (blocks_done <= pass_last) {
+                    publish(blocks_done * kBlockValues, pos);  // the blocks written so far
+                    // what is published is kept in the ring by the waves that expand it; the walk keeps the rest:
+                    // the bytes from the first block without an entry on (one run of this pass holds its first value)
+                    const uint64_t holder = __ballot(starts && b_first <= blocks_done && blocks_done <= b_last);
+                    if (holder != 0) {
+                        const uint32_t l = (uint32_t)__builtin_ctzll(holder);
+                        const uint32_t h_first = __builtin_amdgcn_readlane(first, l);
+                        const uint32_t h_info = __builtin_amdgcn_readlane(info, l);
+                        keep = __builtin_amdgcn_readlane(kind, l) == kBitpacked
+                                   ? h_info + ((blocks_done * kBlockValues - h_first) >> 3) * w
+                                   : __builtin_amdgcn_readlane(after, l);
+                    }
+                }
+            }
+        }
+        produced += total;
+        publish(min(produced, n), pos);
+        keep = pos;
+        PQ2_CLOCK_ADD(5, clock_place);
+        if (produced >= n) {
+            finish(0, pos);
+            break;
+        }
+        if (term != 0u) {
+            finish(term == kPanic ? 5 : 0, pos);  // PQ2_REFERENCE_WOULD_PANIC | the stream is exhausted
+            break;
+        }
+    }
+    // ---- the rest of the stream the expanding waves ask for -----------------------------------------------------
+    const uint64_t clock_tail = PQ2_CLOCK();
+    while (!aborted && issued_hi < final_hi) {
+        uint32_t low_tile = 0;
+        PQ2_SITE(5);
+        wait_room([&](uint32_t lb, uint32_t lt) {
+            low_tile = lt;
+            return lt == 0xffffffffu || issued_hi >= final_hi || room_for_slot(lb);
+        });
+        if (aborted || low_tile == 0xffffffffu) break;  // every tile is done
+        top_up(0xffffffffu, true);
+        while (issued_hi != landed_hi) land();
+    }
+    while (issued_hi != landed_hi) land();  // fills that were still on their way when the walk ended
+    PQ2_CLOCK_ADD(4, clock_tail);
+    PQ2_CLOCK_ADD(0, clock_begin);
+    PQ2_CLOCK_FLUSH(0);
+#ifdef PQ2_RING_TIMING
+    if (lane == 0)
+        for (int i = 0; i < 12; ++i) atomicAdd(&g_ring_clocks[16 + i], (unsigned long long)counts[i]);
+#endif
+}
+
+// ---------------------------------------------------------------------------
+// The expanding waves
+// ---------------------------------------------------------------------------
+struct RingExpander {
+    RingShared sh;
+    uint64_t *slot;    // this wave's word of ctl->expander
+    uint32_t tile;     // the tile it holds
+    uint32_t need;     // the lowest a-offset it has said it still needs (a multiple of 64, kTileFresh, kNoNeed)
+    uint32_t cap;      // bytes behind `need` the walk can always provide
+    int32_t *status;
+    uint32_t page;
+    bool aborted;
+    bool merge;  // see ring_walk's kMerge
+#ifdef PQ2_RING_TIMING
+    uint64_t clocks[8];
+#endif
+
+    __device__ __forceinline__ void say(uint32_t lane) {
+        if (lane == 0)
+            __hip_atomic_store(slot, ((uint64_t)tile << 32) | need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __device__ __forceinline__ void abort_all(uint32_t lane, uint32_t site = 0) {
+#ifdef PQ2_RING_DEBUG
+        if (lane == 0 && lds_load(&sh.ctl->abort) == 0u) status[page] = 200 + (int32_t)site;
+#else
+        if (lane == 0) {  // PQ2_DEVICE_ERROR
+            if (merge)
+                atomicMax(&status[page], 6);
+            else
+                status[page] = 6;
+        }
+#endif
+        lds_store(&sh.ctl->abort, 1u);
+        aborted = true;
+    }
+    // nothing below `from` is needed any more
+    __device__ __forceinline__ void raise_need(uint32_t from, uint32_t lane) {
+        const uint32_t v = from == kEndPos ? kNoNeed : (from & ~63u);
+        if (need == kTileFresh || v > need) {
+            need = v;
+            say(lane);
+        }
+    }
+    // Waits until the ring holds the stream up to `to` (or all it will ever hold); `to` lies within `cap` of `need`.
+    __device__ __forceinline__ void await_bytes(uint32_t to, uint32_t lane) {
+        const uint64_t clock_wait = PQ2_CLOCK();
+        for (uint32_t polls = 0;; ++polls) {
+            const uint32_t landed = lds_load(&sh.ctl->landed);
+            const uint32_t final_hi = lds_load(&sh.ctl->final_hi);
+            if (landed >= min(to, final_hi)) break;
+            if (polls == kRingMaxPolls || lds_load(&sh.ctl->abort) != 0u) {
+                abort_all(lane, 1);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        PQ2_CLOCK_ADD(11, clock_wait);
+        lds_acquire();
+    }
+    // Waits until the walk has covered value `first` (the Resume entry of the block that starts there is written).
+    __device__ __forceinline__ void await_start(uint32_t first, uint32_t lane) {
+        const uint64_t clock_wait = PQ2_CLOCK();
+        for (uint32_t polls = 0;; ++polls) {
+            if (lds_load(&sh.ctl->covered) > first) break;
+            if (polls == kRingMaxPolls || lds_load(&sh.ctl->abort) != 0u) {
+                abort_all(lane, 2);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        PQ2_CLOCK_ADD(9, clock_wait);
+        lds_acquire();
+    }
+    // Number of published runs once a pass from run `ridx` on has what it can get: the walk has covered the span
+    // (values up to `span_end` of the page), or listed 63 runs behind run ridx, or stands still waiting for room
+    // (then whatever is listed has to do).  `must`: run ridx + 1 itself is needed (nothing else is left to do):
+    // then the wave needs no byte below the walk's floor any more and says so.
+    __device__ __forceinline__ uint32_t await_runs(uint32_t ridx, uint32_t span_end, bool must, uint32_t lane) {
+        uint32_t runs = 0;
+        const uint64_t clock_wait = PQ2_CLOCK();
+        for (uint32_t polls = 0;; ++polls) {
+            const uint32_t floor = lds_load(&sh.ctl->floor);  // before the run count: see ring_walk's publish
+            lds_acquire();
+            runs = lds_load(&sh.ctl->runs);
+            const uint32_t covered = lds_load(&sh.ctl->covered);
+            if (covered >= span_end || runs >= ridx + 1u + (kRingTableRuns - 1u)) break;
+            if (runs > ridx + 1u) {
+                if (lds_load(&sh.ctl->blocked) != 0u) break;
+            } else if (must) {
+                raise_need(floor, lane);
+            } else if (lds_load(&sh.ctl->blocked) != 0u) {
+                break;
+            }
+            if (polls == kRingMaxPolls || lds_load(&sh.ctl->abort) != 0u) {
+                abort_all(lane, 3);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        PQ2_CLOCK_ADD(10, clock_wait);
+        lds_acquire();
+        return runs;
+    }
+};
+
+// One wave decodes the span [span_start, span_start + block_n) of a page whose width is W (block_n <=
+// kRingSpanValues) out of the ring.  expand_block of pq2_kernels.hip with the stream window, the header list and
+// the waits replaced: see there for the run table, the chunk index (two bytes per chunk here) and the steps.
+//
+// Where the values go is the sink's business.  IndexSink stores them as they are (u32, the decode of
+// HybridRleDecoder); DictSink<kWords> takes them as indices into a dictionary that lies in LDS and stores the
+// dictionary's values of kWords dwords each (the consumer loop of a dictionary-encoded page,
+// tests/it/read/primitive.rs:99-108 with PrimitivePageDict::value, tests/it/read/dictionary/primitive.rs:20-27).
+// Positions are those of the span; put4 writes the four positions from p on, which lie in one run and begin at a
+// 16-byte boundary of the output, put1 writes one.
+struct IndexSink {
+    out_u32 *out;  // the span's position 0
+    __device__ __forceinline__ uint32_t mis() const { return (uint32_t)(((uintptr_t)out >> 2) & 3u); }
+    __device__ __forceinline__ void put4(const u32x4 v, const int32_t p) { store4(v, out + p); }
+    __device__ __forceinline__ void put1(const uint32_t v, const int32_t p) { out[p] = v; }
+};
+template <int kWords>
+struct DictSink {
+    out_u32 *out;          // the first dword of the value at the span's position 0
+    const uint32_t *dict;  // LDS: dict_len values of kWords dwords
+    uint32_t dict_len;
+    bool bad;              // an index that is not below dict_len was seen (its value is written as zeros)
+    // positions between the 16-byte grid of the output and position 0 (the output is aligned to a whole value)
+    __device__ __forceinline__ uint32_t mis() const {
+        const uint32_t a = (uint32_t)((uintptr_t)out >> 2);
+        return kWords == 1 ? a & 3u : kWords == 2 ? (a >> 1) & 1u : (3u * a) & 3u;
+    }
+    __device__ __forceinline__ void put4(const u32x4 j, const int32_t p) {
+        const uint32_t jj[4] = {j.x, j.y, j.z, j.w};
+        uint32_t v[4 * kWords];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool ok = jj[k] < dict_len;
+            bad |= !ok;
+#pragma unroll
+            for (int c = 0; c < kWords; ++c) v[k * kWords + c] = ok ? dict[jj[k] * kWords + c] : 0u;
+        }
+#pragma unroll
+        for (int c = 0; c < kWords; ++c) {
+            const u32x4 o = {v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]};
+            store4(o, out + (ptrdiff_t)p * kWords + 4 * c);
+        }
+    }
+    __device__ __forceinline__ void put1(const uint32_t j, const int32_t p) {
+        const bool ok = j < dict_len;
+        bad |= !ok;
+#pragma unroll
+        for (int c = 0; c < kWords; ++c) out[(ptrdiff_t)p * kWords + c] = ok ? dict[j * kWords + c] : 0u;
+    }
+};
+
+// `count` positions from 0 on, all of them `value` (a page of width 0, or one without a stream).
+template <typename Sink>
+__device__ __forceinline__ void ring_fill_span(Sink &sink, const uint32_t value, const uint32_t count, const uint32_t lane) {
+    const uint32_t mis = sink.mis();
+    const u32x4 v = {value, value, value, value};
+    const uint32_t q_end = (count + mis + 3u) >> 2;
+    for (uint32_t q = lane; q < q_end; q += 64u) {
+        const int32_t p = (int32_t)(q * 4u) - (int32_t)mis;
+        if (p >= 0 && p + 4 <= (int32_t)count) {
+            sink.put4(v, p);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (p + k >= 0 && p + k < (int32_t)count) sink.put1(value, p + k);
+        }
+    }
+}
+
+template <int W, typename Sink>
+__device__ __forceinline__ void ring_expand_span(RingExpander &io, uint2 *tbl, uint16_t *cidx, const Resume rs,
+                                                 const uint32_t end, const uint32_t n, const uint32_t span_start,
+                                                 const uint32_t block_n, Sink &sink, const uint32_t lane) {
+    constexpr uint32_t w = (uint32_t)W;
+    constexpr uint32_t kLaneRuns = kRingTableRuns - 1;
+    const uint8_t *const ring = io.sh.ring;
+    const uint32_t rmask = io.sh.ring_bytes - 1u;
+    const uint32_t bit_mask = io.sh.ring_bytes * 8u - 1u;
+    const uint32_t max_vals = ((io.cap - 256u) / w) * 8u;  // values of one run the ring surely holds at once
+    const uint32_t span_end = span_start + block_n;
+
+    uint32_t kind = rs.rem_kind >> 31;
+    uint32_t rem = rs.rem_kind & kRemMask;
+    uint32_t payload = rs.payload;  // RLE: the value
+    uint32_t skip = rs.skip;        // bit-packed only
+    uint32_t ridx = rs.run_index;
+
+    const uint32_t mis = sink.mis();
+    uint32_t lo = 0;
+
+    do {
+        // ---- phase 1: the runs that cover [lo, hi) into the table ------------------------------------
+#ifdef PQ2_RING_TIMING
+        uint64_t *const clocks = io.clocks;
+#endif
+        const uint64_t clock_p1 = PQ2_CLOCK();
+        uint32_t take0 = min(rem, block_n - lo);
+        uint32_t y0 = payload;
+        bool alone = take0 == block_n - lo;
+        uint32_t from = kEndPos;  // the first stream byte this pass reads
+        if (kind == kBitpacked) {
+            const uint32_t b_lo = payload + (skip >> 3) * w;
+            if (take0 > max_vals) take0 = max_vals, alone = true;
+            from = b_lo;
+            y0 = b_lo * 8u + (skip & 7u) * w - lo * w;  // ring bit position of block position 0 (taken mod 8R)
+        }
+        uint32_t runs = 0;
+        if (!alone) {
+            runs = io.await_runs(ridx, span_end, false, lane);
+            if (io.aborted) return;
+        }
+        uint32_t hi = lo + take0;
+
+        if (alone && kind == kRle) {  // one value over the whole span: no table, no index, no stream byte
+            const u32x4 v = {payload, payload, payload, payload};
+            const uint32_t q_end = (hi + mis + 3u) >> 2;
+            for (uint32_t q = ((lo + mis) >> 2) + lane; q < q_end; q += 64u) {
+                const int32_t p = (int32_t)(q * 4u) - (int32_t)mis;
+                if (p >= (int32_t)lo && p + 4 <= (int32_t)hi) {
+                    sink.put4(v, p);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (p + k >= (int32_t)lo && p + k < (int32_t)hi) sink.put1(payload, p + k);
+                }
+            }
+        } else {
+            // header positions: lane r <- run ridx + 1 + r, as far as they are published
+            uint32_t hp = kNotYet;
+            if (!alone && lane < kLaneRuns && ridx + 1u + lane < runs) hp = io.sh.hq[(ridx + 1u + lane) & (kHq - 1u)];
+            const uint32_t hp0 = __builtin_amdgcn_readfirstlane(hp);
+            if (kind == kRle && hp0 < kNotYet) from = hp0;
+            // what the pass reads lies behind `from`: say so, and wait for the bytes of the first run (the headers of
+            // published runs have landed: the walk has read them; a bit-packed run further on whose bytes have not
+            // ends the pass and becomes the first run of the next one)
+            uint32_t avail = lds_load(&io.sh.ctl->landed);
+            if (from != kEndPos) {
+                io.raise_need(from, lane);
+                const uint32_t first_end = payload + ((skip + take0 + 7u) >> 3) * w + 8u;
+                if (kind == kBitpacked && avail < min(first_end, lds_load(&io.sh.ctl->final_hi))) {
+                    io.await_bytes(first_end, lane);
+                    if (io.aborted) return;
+                    avail = lds_load(&io.sh.ctl->landed);
+                }
+            }
+            const uint32_t reach = io.need >= kNoNeed ? avail : min(avail, io.need + io.cap);  // bytes this pass may read
+
+#pragma unroll
+            for (uint32_t i = 0; i < kRingSpanChunks * 2u / 1024u; ++i) *(u32x4 *)&cidx[8u * (lane + 64u * i)] = u32x4{0u, 0u, 0u, 0u};
+            if (lane == 0) *(u32x4 *)&cidx[kRingSpanChunks] = u32x4{0u, 0u, 0u, 0u};
+            uint32_t key = kRingNoRun, y = 0;
+            uint32_t start = 0;
+            uint32_t g = 0;
+            if (!alone) {
+                const bool valid = hp < kNotYet;  // a published header: the walk has read it, so it has landed
+                LaneRun run;
+                run.kind = kRle, run.count = 0, run.info = 0;
+                if (valid) run = decode_lane<W>(ring, hp & rmask, hp, end);
+                const uint32_t cnt = min(run.count, 2u * kRingSpanValues);
+                start = hi + wave_inclusive_sum(cnt) - cnt;
+                bool ok = valid;
+                uint32_t value = run.info;
+                if (run.kind == kBitpacked) {
+                    const uint32_t t = start < block_n ? min(run.count, block_n - start) : 0u;
+                    ok = ok && run.info + ((t + 7u) >> 3) * w + 8u <= reach;
+                    value = run.info * 8u - start * w;
+                }
+                const uint64_t bad = __ballot(!ok);  // lane 63 is never valid
+                g = (uint32_t)__builtin_ctzll(bad);
+                const uint32_t start_g = __builtin_amdgcn_readlane(start, g);
+                const uint32_t hp_g = __builtin_amdgcn_readlane(hp, g);
+                const bool ends = g < kLaneRuns && hp_g == kEndPos;  // no more runs: zeros follow (mod.rs:95)
+                if (lane < g && start < block_n) {
+                    key = (start << 1) | run.kind;
+                    y = value;
+                }
+                if (ends && lane == g && start < block_n) key = (start << 1) | kRle;  // y stays 0
+                hi = (start_g >= block_n || ends) ? block_n : start_g;
+            }
+            tbl[(lane + 1u) & 63u] = lane == 63u ? make_uint2((lo << 1) | kind, y0) : make_uint2(key, y);
+            // the table entry of the run before this lane's (lane 0: the pass's first run) and the first position
+            // of the run behind it, for the chunks in which runs start
+            const uint32_t prev_key = __builtin_amdgcn_update_dpp((lo << 1) | kind, key, 0x138, 0xf, 0xf, false);  // wave_shr:1
+            const uint32_t prev_y = __builtin_amdgcn_update_dpp(y0, y, 0x138, 0xf, 0xf, false);
+            const uint32_t next_start = __builtin_amdgcn_update_dpp(
+                0xffffffffu, key != kRingNoRun ? start : 0xffffffffu, 0x130, 0xf, 0xf, false);  // wave_shl:1
+            PQ2_CLOCK_ADD(4, clock_p1);
+            const uint64_t clock_ix = PQ2_CLOCK();
+            // ---- index: the run that holds the first position of every chunk ---------------------------
+            // The runs' first positions ascend with the lane, so do the chunks they mark: of the lanes that mark
+            // one chunk the last one's number is the one to keep, and it is the only one that writes.
+            {
+                const uint32_t c = key != kRingNoRun ? (start + mis + 3u) >> 2 : 0xffffffffu;
+                const uint32_t c_next = __builtin_amdgcn_update_dpp(0xffffffffu, c, 0x130, 0xf, 0xf, false);  // wave_shl:1
+                if (key != kRingNoRun && c != c_next) cidx[c] = (uint16_t)(lane + 1u);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (!alone) {
+                // lane l owns the 8 consecutive chunks from 8 l on: two per dword
+                typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+                u32x4 mm = *(const u32x4 *)&cidx[8u * lane];
+                uint32_t d[4] = {mm.x, mm.y, mm.z, mm.w};
+                uint32_t run_max = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t a = max(d[i] & 0xffffu, run_max);
+                    const uint32_t b = max(d[i] >> 16, a);
+                    run_max = b;
+                    d[i] = a | (b << 16);
+                }
+                const uint32_t upto = wave_inclusive_max(run_max);
+                const uint32_t before = __builtin_amdgcn_update_dpp(0u, upto, 0x138, 0xf, 0xf, false);  // wave_shr:1
+                const u16x2 bb = {(unsigned short)before, (unsigned short)before};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    d[i] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, d[i]), bb));
+                *(u32x4 *)&cidx[8u * lane] = u32x4{d[0], d[1], d[2], d[3]};
+                if (lane == 63u) {  // two more chunks exist when the output is not 16-byte aligned
+                    const uint32_t c0 = max(upto, (uint32_t)cidx[kRingSpanChunks]);
+                    cidx[kRingSpanChunks] = (uint16_t)c0;
+                    cidx[kRingSpanChunks + 1u] = (uint16_t)max(c0, (uint32_t)cidx[kRingSpanChunks + 1u]);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+
+            PQ2_CLOCK_ADD(5, clock_ix);
+            const uint64_t clock_p2 = PQ2_CLOCK();
+            // ---- phase 2: one chunk per lane and step ---------------------------------------------------
+            const uint32_t q_end = (hi + mis + 3u) >> 2;
+            const uint32_t q_first = ((lo + mis) >> 2) + lane;
+            bool ragged = false;
+            constexpr uint32_t kSteps = 4u * kRingSpanBlocks + 1u;
+#pragma unroll
+            for (uint32_t g0 = 0; g0 < kSteps; g0 += kRingStepGroup) {
+                uint32_t j[kRingStepGroup];
+#pragma unroll
+                for (uint32_t i = 0; i < kRingStepGroup; ++i)
+                    if (g0 + i < kSteps) j[i] = cidx[min(q_first + 64u * (g0 + i), kRingChunkSlots - 1u)];
+#pragma unroll
+                for (uint32_t i = 0; i < kRingStepGroup; ++i)
+                    if (g0 + i < kSteps) pin(j[i]);
+                uint2 e[kRingStepGroup];
+                uint32_t nxt[kRingStepGroup];
+#pragma unroll
+                for (uint32_t i = 0; i < kRingStepGroup; ++i)
+                    if (g0 + i < kSteps) e[i] = tbl[j[i]], nxt[i] = tbl[j[i] + 1u].x;
+#pragma unroll
+                for (uint32_t i = 0; i < kRingStepGroup; ++i)
+                    if (g0 + i < kSteps) pin(e[i].x), pin(e[i].y), pin(nxt[i]);
+                FieldWords<W> x[kRingStepGroup];
+#pragma unroll
+                for (uint32_t i = 0; i < kRingStepGroup; ++i)
+                    if (g0 + i < kSteps) {
+                        const int32_t p = (int32_t)((q_first + 64u * (g0 + i)) * 4u) - (int32_t)mis;
+                        x[i] = load_fields<W>(ring, (e[i].y + (uint32_t)p * w) & bit_mask);
+                    }
+#pragma unroll
+                for (uint32_t i = 0; i < kRingStepGroup; ++i)
+                    if (g0 + i < kSteps) x[i].pin_all();
+#pragma unroll
+                for (uint32_t i = 0; i < kRingStepGroup; ++i)
+                    if (g0 + i < kSteps) {
+                        const uint32_t q = q_first + 64u * (g0 + i);
+                        const bool active = q < q_end;
+                        const int32_t p = (int32_t)(q * 4u) - (int32_t)mis;
+                        const bool single = active & (((((uint32_t)(p + 3)) << 1) | 1u) < nxt[i]);
+                        const bool full = (p >= (int32_t)lo) & (p + 4 <= (int32_t)hi);
+                        const u32x4 f = x[i].fields4();
+                        const bool rle = (e[i].x & 1u) != 0u;
+                        const uint32_t r = e[i].y;
+                        const u32x4 v = {rle ? r : f.x, rle ? r : f.y, rle ? r : f.z, rle ? r : f.w};
+                        if (single & full) sink.put4(v, p);
+                        ragged = ragged | (single & !full);
+                    }
+            }
+            PQ2_CLOCK_ADD(6, clock_p2);
+            const uint64_t clock_st = PQ2_CLOCK();
+            if (__builtin_expect(__ballot(ragged) != 0, 0)) {
+#pragma unroll
+                for (uint32_t side = 0; side < 2u; ++side) {
+                    const uint32_t q = side == 0 ? (lo + mis) >> 2 : q_end - 1u;
+                    const int32_t p = (int32_t)(q * 4u) - (int32_t)mis;
+                    const int32_t at = p + (int32_t)(lane & 3u);
+                    const uint32_t j = cidx[q];
+                    const uint2 e = tbl[j];
+                    const uint32_t nxt = tbl[j + 1u].x;
+                    const bool single = ((((uint32_t)(p + 3)) << 1) | 1u) < nxt;
+                    const bool full = p >= (int32_t)lo && p + 4 <= (int32_t)hi;
+                    const uint32_t f = field_at<W>(ring, (e.y + (uint32_t)at * w) & bit_mask);
+                    if (lane < 4u && single && !full && at >= (int32_t)lo && at < (int32_t)hi)
+                        sink.put1((e.x & 1u) ? e.y : f, at);
+                }
+            }
+            // the chunks in which a run starts are left to the lane of that run
+            if (key != kRingNoRun) {
+                const uint32_t q = (start + mis) >> 2;
+                const int32_t p = (int32_t)(q * 4u) - (int32_t)mis;  // p <= start < p + 4
+                const int32_t first_pos = max(p, (int32_t)lo), past = min(p + 4, (int32_t)hi);
+                // the usual case: the run before holds everything in front of this run's first value (its table
+                // entry came over from the lane below), and no further run starts inside the chunk
+                const bool simple = (int32_t)(prev_key >> 1) <= first_pos && next_start >= (uint32_t)past;
+                if (simple) {
+                    uint32_t f[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t pk = (uint32_t)max(p + k, (int32_t)lo);
+                        f[k] = field_at<W>(ring, ((pk >= start ? y : prev_y) + pk * w) & bit_mask);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) pin(f[k]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const bool own = p + k >= (int32_t)start;
+                        const uint32_t ek = own ? key : prev_key, ey = own ? y : prev_y;
+                        if (p + k >= first_pos && p + k < past) sink.put1((ek & 1u) ? ey : f[k], p + k);
+                    }
+                } else {
+                    // the chunk's four positions lie in the run that holds its first position and the up to three
+                    // behind it (runs in the table hold at least one value): their entries, then the four fields
+                    const uint32_t j0 = cidx[q];
+                    uint2 t[5];  // entries j0 .. j0 + 4 (behind the table's end: the sentinel)
+#pragma unroll
+                    for (uint32_t i = 0; i < 5u; ++i) t[i] = tbl[min(j0 + i, kRingTableRuns + 1u)];
+#pragma unroll
+                    for (uint32_t i = 0; i < 5u; ++i) pin(t[i].x), pin(t[i].y);
+                    uint2 cur[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t pk = (uint32_t)max(p + k, (int32_t)lo);
+                        if (((pk << 1) | 1u) >= t[1].x) {  // one step forward is enough: the window moves up
+#pragma unroll
+                            for (uint32_t i = 0; i < 4u; ++i) t[i] = t[i + 1u];
+                        }
+                        cur[k] = t[0];
+                    }
+                    uint32_t f[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t pk = (uint32_t)max(p + k, (int32_t)lo);
+                        f[k] = field_at<W>(ring, (cur[k].y + pk * w) & bit_mask);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) pin(f[k]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (p + k >= first_pos && p + k < past) sink.put1((cur[k].x & 1u) ? cur[k].y : f[k], p + k);
+                }
+            }
+            PQ2_CLOCK_ADD(7, clock_st);
+            // ---- next pass: run ridx + 1 + g becomes the first run -----------------------------------------
+            if (hi < block_n && !alone) {
+                ridx += 1u + g;
+                // everything before that run is written: the wave needs that run's header and nothing below it
+                const uint32_t have = io.await_runs(ridx - 1u, span_end, true, lane);
+                if (io.aborted) return;
+                (void)have;
+                const uint32_t at = __builtin_amdgcn_readfirstlane(io.sh.hq[ridx & (kHq - 1u)]);
+                io.raise_need(at, lane);
+                if (at != kEndPos) {
+                    io.await_bytes(at + 32u, lane);
+                    if (io.aborted) return;
+                }
+                auto rd = [&](uint32_t a) -> uint32_t {
+                    return __builtin_amdgcn_readfirstlane(*(const uint32_t *)&ring[a & rmask]);
+                };
+                const RunInfo run = decode_run(rd, at, end, w, n - (span_start + hi));
+                if (run.kind >= kEnd || run.count == 0) {  // the closing entry: the stream is exhausted, zeros follow
+                    kind = kRle, rem = kRemMask, payload = 0, skip = 0;
+                } else {
+                    kind = run.kind, rem = run.count, skip = 0;
+                    payload = run.kind == kRle ? run.value : run.payload;
+                }
+            }
+        }
+        if (hi < block_n && alone) {  // the first run continues
+            rem -= take0;
+            skip += take0;
+        }
+        lo = hi;
+    } while (lo < block_n);
+}
+
+// Selected rows: see tile_wanted in pq2_kernels.hip.
+__device__ __forceinline__ bool ring_tile_wanted(const PageDev &pg, const uint32_t *__restrict__ tile_mask, uint32_t t) {
+    if (pg.reserved == 0u || tile_mask == nullptr) return true;
+    return ((tile_mask[pg.reserved - 1u + (t >> 5)] >> (t & 31u)) & 1u) != 0u;
+}
+
+constexpr uint32_t kRingCuTickets = 4096;  // entries of the per-compute-unit ticket table (as decode_kernel's)
+
+// Which wave walks: the one on SIMD `ticket % 4` of its compute unit, so that the walks of the workgroups that
+// share a compute unit sit on different SIMDs (see pick_walker in pq2_kernels.hip).  Contains a workgroup barrier.
+__device__ __forceinline__ uint32_t ring_pick_walker(uint32_t *cu_tickets, uint32_t *scratch, const uint32_t wave,
+                                                     const uint32_t lane) {
+    const uint32_t hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_REG_HW_ID
+    const uint32_t xcc_id = __builtin_amdgcn_s_getreg((3 << 11) | 20);  // HW_REG_XCC_ID
+    if (lane == 0) scratch[wave] = (hw_id >> 4) & 3u;                   // SIMD_ID
+    if (threadIdx.x == 0)
+        scratch[7] = atomicAdd(&cu_tickets[(((hw_id >> 8) & 0xffu) | (xcc_id << 8)) & (kRingCuTickets - 1u)], 1u);
+    __syncthreads();
+    const uint32_t target = scratch[7] & 3u;
+    uint32_t walker = 0;
+    for (uint32_t k = kRingExpanders + 1u; k-- > 0;)
+        if (scratch[k] == target) walker = k;
+    return __builtin_amdgcn_readfirstlane(walker);
+}
+
+#ifndef PQ2_RING_MIN_WAVES
+#define PQ2_RING_MIN_WAVES 4
+#endif
+// What ring_kernel<., kWords > 0> needs of a page beside its PageDev (the host's GatherPage).
+struct RingDict {
+    uint64_t idx_addr;   // not used here
+    uint64_t out_addr;   // the page's values, kWords dwords each
+    uint64_t dict_addr;  // the page's dictionary
+    uint32_t dict_len;
+    uint32_t num_values, first_tile, reserved;  // not used here
+};
+constexpr uint32_t kRingDictMaxBits = 12;  // widest index the kernels with a dictionary are built for
+
+// kWords = 0: the page's values are the decoded u32 (IndexSink).  kWords = 1, 2, 3: they are indices into the page's
+// dictionary of kWords-dword values, which the workgroup copies to LDS (from byte `dict_at` of its LDS on) before
+// it starts; `dicts` has a record per page, the statuses must be 0 at the launch.
+template <bool kWide, int kWords>
+__global__ __launch_bounds__(kRingThreads, PQ2_RING_MIN_WAVES) void ring_kernel(const PageDev *__restrict__ pages, uint32_t n_pages,
+                                                       int32_t *__restrict__ status, uint32_t *__restrict__ cu_tickets,
+                                                       uint32_t ring_bytes, const uint32_t *__restrict__ tile_mask,
+                                                       const RingDict *__restrict__ dicts, uint32_t dict_at) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t page = blockIdx.x;
+    if (page >= n_pages) return;
+    const PageDev pg = pages[page];
+    const uint32_t n = pg.num_values;
+    if (n == 0) {
+        if (threadIdx.x == 0 && kWords == 0) status[page] = 0;
+        return;
+    }
+    uint32_t *const dict_lds = (uint32_t *)(lds + dict_at);
+    uint32_t dict_len = 0;
+    uint64_t value_addr = 0;
+    if constexpr (kWords != 0) {
+        const RingDict dp = dicts[page];
+        dict_len = dp.dict_len;
+        value_addr = dp.out_addr;
+        typedef __attribute__((address_space(1))) const uint32_t gu32;
+        for (uint32_t i = threadIdx.x; i < dp.dict_len * (uint32_t)kWords; i += kRingThreads) dict_lds[i] = ((gu32 *)dp.dict_addr)[i];
+    }  // (the barrier inside ring_pick_walker below is also the one behind this copy)
+    RingShared sh;
+    sh.ring = lds;
+    sh.ring_bytes = ring_bytes;
+    sh.hq = (uint32_t *)(lds + ring_bytes + kMirror);
+    sh.rq = (Resume *)(lds + ring_bytes + kMirror + kHq * 4u);
+    sh.ctl = (RingCtl *)(lds + ring_bytes + kMirror + kHq * 4u + kRq * 16u);
+    uint8_t *const tables = (uint8_t *)sh.ctl + sizeof(RingCtl);
+    const uint32_t n_tiles = (n + kRingTileValues - 1u) / kRingTileValues;
+    if (threadIdx.x < sizeof(RingCtl) / 4u) ((uint32_t *)sh.ctl)[threadIdx.x] = 0u;
+    __syncthreads();
+    if (threadIdx.x < kRingExpanders)  // the first tiles are handed out here: wave e holds tile e
+        sh.ctl->expander[threadIdx.x] = ((uint64_t)threadIdx.x << 32) | kTileFresh;
+    if (threadIdx.x == 0) sh.ctl->next_tile = kRingExpanders;
+    const uint32_t walker = ring_pick_walker(cu_tickets, sh.ctl->pick, wave, lane);  // with a workgroup barrier inside
+
+    if (wave == walker) {
+        if (PQ2_RING_WALK_PRIO != 0) __builtin_amdgcn_s_setprio(PQ2_RING_WALK_PRIO);
+        ring_walk<kWide, kWords != 0>(pg, page, sh, status, lane);
+        return;
+    }
+    const uint32_t e = wave - (wave > walker ? 1u : 0u);
+    uint2 *tbl = (uint2 *)tables + e * (kRingTableRuns + 2u);
+    uint16_t *cidx = (uint16_t *)(tables + kRingExpanders * (kRingTableRuns + 2u) * 8u) + e * kRingChunkSlots;
+    if (lane < 2) tbl[kRingTableRuns + lane] = make_uint2(kRingNoRun, 0u);  // read by tbl[j + 1] only
+
+    RingExpander io;
+    io.sh = sh;
+    io.slot = &sh.ctl->expander[e];
+    io.cap = ring_bytes - 2u * kSlot;
+    io.status = status;
+    io.page = page;
+    io.aborted = false;
+    io.merge = kWords != 0;
+    bool bad_index = false;
+#ifdef PQ2_RING_TIMING
+    for (int i = 0; i < 8; ++i) io.clocks[i] = 0;
+    uint64_t *const clocks = io.clocks;
+#endif
+    const uint32_t w = pg.num_bits;
+    const uint32_t delta = (uint32_t)(pg.in_addr & 15u);
+    const uint32_t end = delta + pg.in_len;
+
+    const uint64_t clock_begin = PQ2_CLOCK();
+    for (uint32_t t = e; t < n_tiles;) {
+        io.tile = t;
+        io.need = kTileFresh;
+        io.say(lane);
+        if (ring_tile_wanted(pg, tile_mask, t * kRingTileBlocks / kBlocksPerTile)) {
+            const uint32_t tile_first = t * kRingTileValues;
+            out_u32 *const out = (out_u32 *)pg.out_addr + tile_first;
+            constexpr uint32_t kSpans = kRingTileBlocks / kRingSpanBlocks;
+            for (uint32_t i = 0; i < kSpans; ++i) {
+                const uint32_t span_first = tile_first + i * kRingSpanValues;
+                if (span_first >= n) break;
+                const uint32_t span_n = min(kRingSpanValues, n - span_first);
+                io.await_start(span_first, lane);
+                if (io.aborted) return;
+                const u32x4 r4 = *(const u32x4 *)&sh.rq[(t * kRingTileBlocks + i * kRingSpanBlocks) & (kRq - 1u)];
+                Resume rs;
+                rs.run_index = __builtin_amdgcn_readfirstlane(r4.x);
+                rs.rem_kind = __builtin_amdgcn_readfirstlane(r4.y);
+                rs.payload = __builtin_amdgcn_readfirstlane(r4.z);
+                rs.skip = __builtin_amdgcn_readfirstlane(r4.w);
+                // the lowest byte the span (and everything behind it) can ask for: the group that holds a
+                // bit-packed run's first value here, or the byte behind an RLE run
+                io.raise_need((rs.rem_kind >> 31) == kBitpacked ? rs.payload + (rs.skip >> 3) * w : rs.skip, lane);
+#define PQ2_W(N)                                                                           \
+    case N:                                                                                \
+        ring_expand_span<N>(io, tbl, cidx, rs, end, n, span_first, span_n, sink, lane);    \
+        break;
+                if constexpr (kWords == 0) {
+                    IndexSink sink = {out + i * kRingSpanValues};
+                    switch (w) {
+#ifdef PQ2_ONLY_W
+                        PQ2_W(PQ2_ONLY_W)
+#else
+                        PQ2_W(1) PQ2_W(2) PQ2_W(3) PQ2_W(4) PQ2_W(5) PQ2_W(6) PQ2_W(7) PQ2_W(8)
+                        PQ2_W(9) PQ2_W(10) PQ2_W(11) PQ2_W(12) PQ2_W(13) PQ2_W(14) PQ2_W(15) PQ2_W(16)
+                        PQ2_W(17) PQ2_W(18) PQ2_W(19) PQ2_W(20) PQ2_W(21) PQ2_W(22) PQ2_W(23) PQ2_W(24)
+                        PQ2_W(25) PQ2_W(26) PQ2_W(27) PQ2_W(28) PQ2_W(29) PQ2_W(30) PQ2_W(31) PQ2_W(32)
+#endif
+                        default:  // width 0 (or beyond 32, whose page has no values): zeros
+                            ring_fill_span(sink, 0u, span_n, lane);
+                            break;
+                    }
+                } else {
+                    DictSink<kWords> sink = {(out_u32 *)value_addr + (size_t)span_first * kWords, dict_lds, dict_len, false};
+                    static_assert(kRingDictMaxBits == 12, "the cases below");
+                    switch (w) {
+                        PQ2_W(1) PQ2_W(2) PQ2_W(3) PQ2_W(4) PQ2_W(5) PQ2_W(6) PQ2_W(7) PQ2_W(8)
+                        PQ2_W(9) PQ2_W(10) PQ2_W(11) PQ2_W(12)
+                        case 0:  // every index is 0
+                            ring_fill_span(sink, 0u, span_n, lane);
+                            break;
+                        default:  // the host does not send wider pages here
+                            io.abort_all(lane, 9);
+                            break;
+                    }
+                    bad_index |= sink.bad;
+                }
+#undef PQ2_W
+                if (io.aborted) return;
+            }
+        }
+        // the next tile nobody holds
+        uint32_t next = 0;
+        if (lane == 0) next = atomicAdd(&sh.ctl->next_tile, 1u);
+        t = __builtin_amdgcn_readfirstlane(next);
+    }
+    io.tile = 0xffffffffu;  // through: the walk no longer counts on this wave
+    io.need = kNoNeed;
+    io.say(lane);
+    if (kWords != 0 && __ballot(bad_index) != 0 && lane == 0) atomicMax(&status[page], 1);  // PQ2_OUT_OF_SPEC
+    PQ2_CLOCK_ADD(8, clock_begin);
+    PQ2_CLOCK_FLUSH(8);
+}
+
+}  // namespace pq2

@@ -1,0 +1,54 @@
+// ring_kernel with the dictionary lookup inside: the launcher (the kernel itself: pq2_ring.h).
+//
+// The expanding waves of ring_kernel hold every decoded value in a register just before they store it.  For a
+// dictionary-encoded page that value is an index, and what the reader wants is the dictionary's value at that
+// index (tests/it/read/primitive.rs:99-108): with the page's dictionary in LDS the lookup happens there, between
+// the extraction and the store, and the indices never exist in device memory.
+#include "pq2_ring.h"
+
+extern "C" uint32_t pq2_ring_dict_max_bits() { return pq2::kRingDictMaxBits; }
+// the largest dictionary (bytes) a workgroup keeps in LDS beside its ring
+extern "C" uint32_t pq2_ring_dict_max_bytes() { return 49152u; }
+
+// `dicts`: one pq2::RingDict per page (device); `value_words`: 1, 2 or 3; `max_dict_bytes`: of the largest
+// dictionary of the batch (at most pq2_ring_dict_max_bytes()); every page is at most pq2_ring_dict_max_bits() wide.
+// The statuses must have been cleared on `stream`.
+extern "C" hipError_t pq2_launch_ring_dict(const void *pages, uint32_t n_pages, int32_t *status, uint32_t *cu_tickets,
+                                           const uint32_t *tile_mask, const void *dicts, uint32_t value_words,
+                                           uint32_t max_dict_bytes, hipStream_t stream) {
+    if (n_pages == 0) return hipSuccess;
+    const uint32_t dict_bytes = (max_dict_bytes + 15u) & ~15u;
+    // The ring of 32 KiB where three workgroups still share a compute unit's LDS (dictionaries up to 13 KiB); up to
+    // 16 KiB the ring of 16 KiB keeps four workgroups there; beyond that two workgroups fit either way (one from
+    // 40 KiB on: still ahead of a second pass over the indices).
+    uint32_t ring_bytes = 3u * (pq2::ring_lds_bytes(32768u) + dict_bytes) <= 160u * 1024u ? 32768u
+                          : dict_bytes <= 16384u                                          ? 16384u
+                                                                                          : 32768u;
+    if (const char *v = getenv("PQ2_RING_BYTES")) {  // tuning knob
+        const uint32_t b = (uint32_t)atoi(v);
+        if (b == 16384u || b == 32768u) ring_bytes = b;
+    }
+    const uint32_t dict_at = pq2::ring_lds_bytes(ring_bytes);
+    static_assert(pq2::ring_lds_bytes(16384u) % 16u == 0u, "the dictionary begins at a 16-byte boundary");
+    const uint32_t lds_bytes = dict_at + dict_bytes;
+#define PQ2_LAUNCH(WORDS)                                                                                             \
+    if (lds_bytes > 65536u) { /* more than 64 KiB of dynamic LDS has to be asked for */                               \
+        hipError_t e = hipFuncSetAttribute((const void *)pq2::ring_kernel<false, WORDS>,                              \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);              \
+        if (e != hipSuccess) return e;                                                                                \
+    }                                                                                                                 \
+    hipLaunchKernelGGL((pq2::ring_kernel<false, WORDS>), dim3(n_pages), dim3(pq2::kRingThreads), lds_bytes, stream,   \
+                       (const pq2::PageDev *)pages, n_pages, status, cu_tickets, ring_bytes, tile_mask,               \
+                       (const pq2::RingDict *)dicts, dict_at)
+    if (value_words == 1u) {
+        PQ2_LAUNCH(1);
+    } else if (value_words == 2u) {
+        PQ2_LAUNCH(2);
+    } else if (value_words == 3u) {
+        PQ2_LAUNCH(3);
+    } else {
+        return hipErrorInvalidValue;
+    }
+#undef PQ2_LAUNCH
+    return hipGetLastError();
+}

@@ -77,6 +77,74 @@ def test_gather_matches_oracle(ctx, oracle, value_size):
     assert (got[~covered] == 0x5A5A5A5A).all()  # the gaps between pages are never written
 
 
+@pytest.mark.parametrize("value_size", [4, 8, 12])
+def test_lookup_inside_the_decode_kernel(ctx, oracle, value_size):
+    """Pages of at most 12 bits with dictionaries of at most 48 KiB: where ring_kernel decodes the batch, the lookup
+    happens inside it (no buffer of indices).  Every kind of span: long RLE runs, mixed runs, width 0, pages that end
+    inside the stream and behind it, values at every alignment the value size allows, a dictionary that misses
+    indices, a stream on which the reference panics."""
+    rng = np.random.default_rng(200 + value_size)
+    words = value_size // 4
+    batch = synth.PageBatch(align=1)
+    pages, tables, refs = [], [], []
+    dict_off = 0
+    shapes = [(1, 200001, 400.0, 30.0), (2, 50000, 3.0, 5.0), (3, 4096, 20.0, 90.0), (7, 9000, 20.0, 90.0),
+              (10, 65536, 64.0, 256.0), (12, 300000, 64.0, 256.0), (12, 123, 2.0, 9.0), (0, 777, 0, 0),
+              (9, 30000, 1000.0, 8.0), (11, 70000, 5.0, 600.0), (5, 1, 1.0, 1.0), (4, 40000, 1.5, 2.0)]
+    for p, (w, n, rep, dist) in enumerate(shapes * 2):
+        stream = synth.dict_page(synth.seed_for(2, 80 + p), n, w, rep, dist)[0] if w else np.zeros(0, dtype=np.uint8)
+        want = n + 50 if p % 3 == 0 else n if p % 3 == 1 else max(1, n // 2)
+        if p == 13:  # an RLE run whose value byte is missing: the reference panics (decoder.rs:59-60)
+            stream = np.array([0x10, 0x01], dtype=np.uint8)
+            w, want = 12, 64
+        batch.chunks.append(np.zeros(1 + p % 4, np.uint8))
+        batch.in_bytes += 1 + p % 4
+        batch.add(stream, w, want, out_align=1 + (p % 3))
+        dict_len = max(1 << w, 1)
+        if value_size * dict_len > 49152:
+            dict_len = 49152 // value_size
+        if p == 9:
+            dict_len = 20  # misses most indices of a 7-bit page
+        table = rng.integers(0, 1 << 32, size=(dict_len, words), dtype=np.uint64).astype(np.uint32)
+        dict_off += (-dict_off) % 8
+        refs.append((dict_off, dict_len, 0))
+        tables.append((dict_off, table))
+        dict_off += table.nbytes
+        pages.append((stream, w, want, table))
+    # enough pages for the schedule batches of many pages get
+    for p in range(100):
+        stream, _ = synth.dict_page(synth.seed_for(2, 300 + p), 20000 + p, 8, 10.0, 40.0)
+        batch.add(stream, 8, 20000 + p, out_align=1)
+        refs.append(refs[3])
+        pages.append((stream, 8, 20000 + p, tables[3][1]))
+    data, descs, out_values = batch.finish()
+    dict_bytes = np.zeros(dict_off + 8, dtype=np.uint8)
+    for off, table in tables:
+        dict_bytes[off:off + table.nbytes] = table.view(np.uint8).reshape(-1)
+    got, status = run(ctx, data, descs, out_values, dict_bytes, np.array(refs, dtype=DICT_REF_DTYPE), value_size)
+    if ctx.last_schedule().startswith("ring_kernel"):
+        assert ctx.last_schedule() == "ring_kernel+dictionary"
+    covered = np.zeros(out_values, dtype=bool)
+    seen = set()
+    for k, (d, (stream, w, n, table)) in enumerate(zip(descs, pages)):
+        st, idx = oracle.hybrid_rle_decode(stream, w, n)
+        o = int(d["out_off"])
+        covered[o:o + n] = True
+        if st != OK:
+            assert status[k] == st, k
+            seen.add(st)
+            continue
+        ok = idx < len(table)
+        assert status[k] == (OK if ok.all() else OUT_OF_SPEC), k
+        seen.add(int(status[k]))
+        want = np.zeros((n, words), dtype=np.uint32)
+        want[ok] = table[idx[ok]]
+        bad = np.nonzero((got[o:o + n] != want).any(axis=1))[0]
+        assert bad.size == 0, ("page", k, "w", w, "first mismatch at", bad[:5])
+    assert seen == {OK, OUT_OF_SPEC, REFERENCE_WOULD_PANIC}
+    assert (got[~covered] == 0x5A5A5A5A).all()  # the gaps between pages are never written
+
+
 def test_index_beyond_the_dictionary_fails_the_page_only(ctx, oracle):
     batch = synth.PageBatch()
     n = 20000

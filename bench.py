@@ -439,6 +439,11 @@ def main():
         rounds = max(expand_launches // max(batches, 1), 1)
         expand_avg_ms = expand_ms / max(expand_launches, 1)
         bytes_per_launch = (in_bytes_alg + out_bytes) / rounds
+        scouted = "+" in schedule
+        if scouted:
+            # the header walk (seven small launches) and the expansion are the hot path together: priced as one unit
+            kernel_name = schedule
+            expand_avg_ms = (parse_ms + expand_ms) / max(batches, 1)
         achieved = bytes_per_launch / (expand_avg_ms * 1e-3) / 1e9
         workload_key = {"workload": args.workload, "pages_per_gpu": args.pages, "values_per_page": n,
                         "num_bits": args.bits if args.workload != "def" else 1}
@@ -471,7 +476,7 @@ def main():
                 "algorithmic_bytes_per_launch": int(bytes_per_launch),
                 "avg_launch_ms": round(expand_avg_ms, 4), "launches_per_step": rounds,
                 "parse_kernel_ms_per_step": round(parse_ms / max(batches, 1), 4),
-                "%s_ms_per_step" % kernel_name: round(expand_ms / max(batches, 1), 4),
+                "%s_ms_per_step" % schedule.split("+")[-1]: round(expand_ms / max(batches, 1), 4),
             },
         }
         if world == 1 and not args.no_cpu_baseline:

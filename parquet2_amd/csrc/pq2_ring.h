@@ -63,10 +63,22 @@ constexpr uint32_t kRingMaxPolls = 1u << 22;    // of >= 0.1 us each: far beyond
 constexpr uint32_t kRingTileBlocks = PQ2_RING_TILE_BLOCKS;  // 2 or 4
 constexpr uint32_t kRingTileValues = kRingTileBlocks * kBlockValues;
 constexpr uint32_t kRingTableRuns = 64;                      // run-table entries per expanding wave
-constexpr uint32_t kRingSpanBlocks = 2;                      // blocks per span
+#ifndef PQ2_RING_SPAN_BLOCKS
+#define PQ2_RING_SPAN_BLOCKS 2
+#endif
+// What an expanding wave builds one run table and one chunk index for: 2 blocks with two bytes per chunk-index
+// entry, or 4 blocks (a whole tile: half as many table builds) with one byte per entry -- the same LDS either way.
+constexpr uint32_t kRingSpanBlocks = PQ2_RING_SPAN_BLOCKS;   // blocks per span: 2 or 4
+static_assert(kRingSpanBlocks == 2 || (kRingSpanBlocks == 4 && PQ2_RING_TILE_BLOCKS == 4), "spans of 2 or 4 blocks");
 constexpr uint32_t kRingSpanValues = kRingSpanBlocks * kBlockValues;
 constexpr uint32_t kRingSpanChunks = kRingSpanValues / 4u;   // 16-byte output chunks per span
+#if PQ2_RING_SPAN_BLOCKS == 4
+typedef uint8_t ring_cidx_t;                                 // (a table has at most 64 runs)
+constexpr uint32_t kRingChunkSlots = kRingSpanChunks + 16u;  // + 2 when the output is not 16-byte aligned, rounded up
+#else
+typedef uint16_t ring_cidx_t;
 constexpr uint32_t kRingChunkSlots = kRingSpanChunks + 8u;   // + 2 when the output is not 16-byte aligned, rounded up
+#endif
 constexpr uint32_t kRingNoRun = 0xffffffffu;
 #ifndef PQ2_RING_STEP_GROUP
 #define PQ2_RING_STEP_GROUP 5
@@ -110,7 +122,7 @@ __device__ unsigned long long g_ring_clocks[32];  // 16..: event counts of the w
 // LDS bytes of one workgroup for a ring of `ring_bytes`
 __host__ __device__ constexpr uint32_t ring_lds_bytes(uint32_t ring_bytes) {
     return ring_bytes + kMirror + kHq * 4u + kRq * 16u + (uint32_t)sizeof(RingCtl) +
-           kRingExpanders * ((kRingTableRuns + 2u) * 8u + kRingChunkSlots * 2u);
+           kRingExpanders * ((kRingTableRuns + 2u) * 8u + kRingChunkSlots * (uint32_t)sizeof(ring_cidx_t));
 }
 
 __device__ __forceinline__ uint32_t lds_load(const uint32_t *p) {
@@ -774,7 +786,7 @@ __device__ __forceinline__ void ring_fill_span(Sink &sink, const uint32_t value,
 }
 
 template <int W, typename Sink>
-__device__ __forceinline__ void ring_expand_span(RingExpander &io, uint2 *tbl, uint16_t *cidx, const Resume rs,
+__device__ __forceinline__ void ring_expand_span(RingExpander &io, uint2 *tbl, ring_cidx_t *cidx, const Resume rs,
                                                  const uint32_t end, const uint32_t n, const uint32_t span_start,
                                                  const uint32_t block_n, Sink &sink, const uint32_t lane) {
     constexpr uint32_t w = (uint32_t)W;
@@ -852,7 +864,8 @@ __device__ __forceinline__ void ring_expand_span(RingExpander &io, uint2 *tbl, u
             const uint32_t reach = io.need >= kNoNeed ? avail : min(avail, io.need + io.cap);  // bytes this pass may read
 
 #pragma unroll
-            for (uint32_t i = 0; i < kRingSpanChunks * 2u / 1024u; ++i) *(u32x4 *)&cidx[8u * (lane + 64u * i)] = u32x4{0u, 0u, 0u, 0u};
+            for (uint32_t i = 0; i < kRingSpanChunks * (uint32_t)sizeof(ring_cidx_t) / 1024u; ++i)
+                *(u32x4 *)((uint8_t *)cidx + 16u * (lane + 64u * i)) = u32x4{0u, 0u, 0u, 0u};
             if (lane == 0) *(u32x4 *)&cidx[kRingSpanChunks] = u32x4{0u, 0u, 0u, 0u};
             uint32_t key = kRingNoRun, y = 0;
             uint32_t start = 0;
@@ -898,10 +911,46 @@ __device__ __forceinline__ void ring_expand_span(RingExpander &io, uint2 *tbl, u
             {
                 const uint32_t c = key != kRingNoRun ? (start + mis + 3u) >> 2 : 0xffffffffu;
                 const uint32_t c_next = __builtin_amdgcn_update_dpp(0xffffffffu, c, 0x130, 0xf, 0xf, false);  // wave_shl:1
-                if (key != kRingNoRun && c != c_next) cidx[c] = (uint16_t)(lane + 1u);
+                if (key != kRingNoRun && c != c_next) cidx[c] = (ring_cidx_t)(lane + 1u);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+#if PQ2_RING_SPAN_BLOCKS == 4
+            if (!alone) {
+                // lane l owns the 16 consecutive chunks from 16 l on: four per dword
+                typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+                const u32x4 mm = *(const u32x4 *)&cidx[16u * lane];
+                uint32_t d[4] = {mm.x, mm.y, mm.z, mm.w};
+                // the largest of the lane's sixteen (even and odd bytes as pairs of 16-bit numbers)
+                u16x2 most = {0, 0};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    most = __builtin_elementwise_max(most, __builtin_bit_cast(u16x2, d[i] & 0x00ff00ffu));
+                    most = __builtin_elementwise_max(most, __builtin_bit_cast(u16x2, (d[i] >> 8) & 0x00ff00ffu));
+                }
+                const uint32_t run_max = max((uint32_t)most.x, (uint32_t)most.y);
+                const uint32_t upto = wave_inclusive_max(run_max);
+                uint32_t run = __builtin_amdgcn_update_dpp(0u, upto, 0x138, 0xf, 0xf, false);  // wave_shr:1
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    uint32_t o = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        run = max(run, (d[i] >> (8 * k)) & 0xffu);
+                        o |= run << (8 * k);
+                    }
+                    d[i] = o;
+                }
+                *(u32x4 *)&cidx[16u * lane] = u32x4{d[0], d[1], d[2], d[3]};
+                if (lane == 63u) {  // two more chunks exist when the output is not 16-byte aligned
+                    const uint32_t c0 = max(upto, (uint32_t)cidx[kRingSpanChunks]);
+                    cidx[kRingSpanChunks] = (ring_cidx_t)c0;
+                    cidx[kRingSpanChunks + 1u] = (ring_cidx_t)max(c0, (uint32_t)cidx[kRingSpanChunks + 1u]);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+#else
             if (!alone) {
                 // lane l owns the 8 consecutive chunks from 8 l on: two per dword
                 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
@@ -924,13 +973,14 @@ __device__ __forceinline__ void ring_expand_span(RingExpander &io, uint2 *tbl, u
                 *(u32x4 *)&cidx[8u * lane] = u32x4{d[0], d[1], d[2], d[3]};
                 if (lane == 63u) {  // two more chunks exist when the output is not 16-byte aligned
                     const uint32_t c0 = max(upto, (uint32_t)cidx[kRingSpanChunks]);
-                    cidx[kRingSpanChunks] = (uint16_t)c0;
-                    cidx[kRingSpanChunks + 1u] = (uint16_t)max(c0, (uint32_t)cidx[kRingSpanChunks + 1u]);
+                    cidx[kRingSpanChunks] = (ring_cidx_t)c0;
+                    cidx[kRingSpanChunks + 1u] = (ring_cidx_t)max(c0, (uint32_t)cidx[kRingSpanChunks + 1u]);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             }
 
+#endif
             PQ2_CLOCK_ADD(5, clock_ix);
             const uint64_t clock_p2 = PQ2_CLOCK();
             // ---- phase 2: one chunk per lane and step ---------------------------------------------------
@@ -1178,7 +1228,7 @@ __global__ __launch_bounds__(kRingThreads, PQ2_RING_MIN_WAVES) void ring_kernel(
     }
     const uint32_t e = wave - (wave > walker ? 1u : 0u);
     uint2 *tbl = (uint2 *)tables + e * (kRingTableRuns + 2u);
-    uint16_t *cidx = (uint16_t *)(tables + kRingExpanders * (kRingTableRuns + 2u) * 8u) + e * kRingChunkSlots;
+    ring_cidx_t *cidx = (ring_cidx_t *)(tables + kRingExpanders * (kRingTableRuns + 2u) * 8u) + e * kRingChunkSlots;
     if (lane < 2) tbl[kRingTableRuns + lane] = make_uint2(kRingNoRun, 0u);  // read by tbl[j + 1] only
 
     RingExpander io;

@@ -26,9 +26,22 @@ run_case bitunpack --workload bitunpack --steps 10 || exit 1
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --no-cpu-baseline --steps 2 --warmup 1 > $O/pmc_fetch.log 2>&1 || exit 1
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py --no-cpu-baseline --steps 2 --warmup 1 > $O/pmc_write.log 2>&1 || exit 1
 timeout -k 10 200 python3 $R/bench.py --host-path --pages 512 --steps 5 > $O/host_path.json 2> $O/host_path.err || exit 1
+# dictionary values: the lookup inside ring_kernel against the two passes, bench lines and memory-side traffic (4-byte values)
+run_case def64 --workload def --pages 64 --values 65536 || exit 1
+(cd $R && tools/bench_gather.sh && cp gpurun_out/gather_bench.txt $O/gather.txt) || exit 1
+for fused in 1 0; do
+  for c in FETCH_SIZE WRITE_SIZE; do
+    PQ2_FUSED_GATHER=$fused timeout -s KILL 200 rocprofv3 --pmc $c --output-format csv -d $O/pmc_gather_${fused}_$c -- python3 $R/bench.py --pages 1024 --distinct 64 --gather-bytes 4 --steps 2 --warmup 1 > $O/pmc_gather_${fused}_$c.log 2>&1 || exit 1
+  done
+done
+timeout -k 10 200 python3 $R/tools/scout_rounds.py > $O/scout_rounds.txt 2>&1 || exit 1
 cd $R
 python3 tools/traffic.py $O/pmc_fetch $O/pmc_write 4 $O/traffic.json '{"workload": "dict", "pages_per_gpu": 2048, "values_per_page": 1048576, "num_bits": 12}' > /dev/null
 cp $(find $O/pmc_fetch -name '*counter_collection.csv' | head -1) $O/pmc_fetch_size.csv
 cp $(find $O/pmc_write -name '*counter_collection.csv' | head -1) $O/pmc_write_size.csv
 rm -rf $O/pmc_fetch $O/pmc_write
+for fused in 1 0; do
+  python3 tools/traffic.py $O/pmc_gather_${fused}_FETCH_SIZE $O/pmc_gather_${fused}_WRITE_SIZE 4 $O/gather_traffic_fused$fused.json '{"workload": "dict + 4-byte dictionary values", "pages_per_gpu": 1024, "values_per_page": 1048576, "num_bits": 12, "lookup_inside_ring_kernel": '$fused'}' > /dev/null
+  rm -rf $O/pmc_gather_${fused}_FETCH_SIZE $O/pmc_gather_${fused}_WRITE_SIZE
+done
 for f in $O/bench_*.json $O/host_path.json; do echo "== $f"; cut -c1-400 $f; done

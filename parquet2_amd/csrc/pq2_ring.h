@@ -22,6 +22,8 @@
 #pragma once
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "pq2_device.h"
 
 namespace pq2 {
@@ -63,22 +65,28 @@ constexpr uint32_t kRingMaxPolls = 1u << 22;    // of >= 0.1 us each: far beyond
 constexpr uint32_t kRingTileBlocks = PQ2_RING_TILE_BLOCKS;  // 2 or 4
 constexpr uint32_t kRingTileValues = kRingTileBlocks * kBlockValues;
 constexpr uint32_t kRingTableRuns = 64;                      // run-table entries per expanding wave
-#ifndef PQ2_RING_SPAN_BLOCKS
-#define PQ2_RING_SPAN_BLOCKS 2
+// What an expanding wave builds one run table and one chunk index for: a span of 2 blocks, with two bytes per
+// chunk-index entry -- or, for pages of at most kRingWholeTileBits bits (definition and repetition levels: long
+// RLE runs, little of the ring in use), the whole tile of 4 blocks with one byte per entry: half as many spans to
+// set up, and the same LDS.  (Measured: config 3 gains 8 %; config-2 pages lose 12 % with whole-tile spans, because
+// a wave then holds on to the ring bytes of a whole tile.)
+constexpr uint32_t kRingSpanBlocks = 2;
+#ifndef PQ2_RING_WHOLE_TILE_BITS
+#define PQ2_RING_WHOLE_TILE_BITS 2
 #endif
-// What an expanding wave builds one run table and one chunk index for: 2 blocks with two bytes per chunk-index
-// entry, or 4 blocks (a whole tile: half as many table builds) with one byte per entry -- the same LDS either way.
-constexpr uint32_t kRingSpanBlocks = PQ2_RING_SPAN_BLOCKS;   // blocks per span: 2 or 4
-static_assert(kRingSpanBlocks == 2 || (kRingSpanBlocks == 4 && PQ2_RING_TILE_BLOCKS == 4), "spans of 2 or 4 blocks");
-constexpr uint32_t kRingSpanValues = kRingSpanBlocks * kBlockValues;
-constexpr uint32_t kRingSpanChunks = kRingSpanValues / 4u;   // 16-byte output chunks per span
-#if PQ2_RING_SPAN_BLOCKS == 4
-typedef uint8_t ring_cidx_t;                                 // (a table has at most 64 runs)
-constexpr uint32_t kRingChunkSlots = kRingSpanChunks + 16u;  // + 2 when the output is not 16-byte aligned, rounded up
-#else
-typedef uint16_t ring_cidx_t;
-constexpr uint32_t kRingChunkSlots = kRingSpanChunks + 8u;   // + 2 when the output is not 16-byte aligned, rounded up
-#endif
+constexpr uint32_t kRingWholeTileBits = PQ2_RING_WHOLE_TILE_BITS;  // 0, 1 or 2
+static_assert(kRingTileBlocks == 4 || kRingTileBlocks == 2, "tiles of 2 or 4 blocks");
+template <uint32_t kBlocks>
+struct RingSpan {
+    static_assert(kBlocks == 2 || kBlocks == 4, "spans of 2 or 4 blocks");
+    static constexpr uint32_t kValues = kBlocks * kBlockValues;
+    static constexpr uint32_t kChunks = kValues / 4u;  // 16-byte output chunks per span
+    // + 2 chunks when the output is not 16-byte aligned, rounded up to 16 bytes of entries
+    static constexpr uint32_t kSlots = kChunks + (kBlocks == 4 ? 16u : 8u);
+    typedef typename std::conditional<kBlocks == 4, uint8_t, uint16_t>::type cidx_t;  // (a table has at most 64 runs)
+    static constexpr uint32_t kBytes = kSlots * (uint32_t)sizeof(cidx_t);
+};
+static_assert(RingSpan<2>::kBytes == RingSpan<4>::kBytes, "either chunk index fits the same LDS");
 constexpr uint32_t kRingNoRun = 0xffffffffu;
 #ifndef PQ2_RING_STEP_GROUP
 #define PQ2_RING_STEP_GROUP 5
@@ -122,7 +130,7 @@ __device__ unsigned long long g_ring_clocks[32];  // 16..: event counts of the w
 // LDS bytes of one workgroup for a ring of `ring_bytes`
 __host__ __device__ constexpr uint32_t ring_lds_bytes(uint32_t ring_bytes) {
     return ring_bytes + kMirror + kHq * 4u + kRq * 16u + (uint32_t)sizeof(RingCtl) +
-           kRingExpanders * ((kRingTableRuns + 2u) * 8u + kRingChunkSlots * (uint32_t)sizeof(ring_cidx_t));
+           kRingExpanders * ((kRingTableRuns + 2u) * 8u + RingSpan<2>::kBytes);
 }
 
 __device__ __forceinline__ uint32_t lds_load(const uint32_t *p) {
@@ -785,10 +793,15 @@ __device__ __forceinline__ void ring_fill_span(Sink &sink, const uint32_t value,
     }
 }
 
-template <int W, typename Sink>
-__device__ __forceinline__ void ring_expand_span(RingExpander &io, uint2 *tbl, ring_cidx_t *cidx, const Resume rs,
+template <int W, uint32_t kSpanBlocks, typename Sink>
+__device__ __forceinline__ void ring_expand_span(RingExpander &io, uint2 *tbl, void *cidx_lds, const Resume rs,
                                                  const uint32_t end, const uint32_t n, const uint32_t span_start,
                                                  const uint32_t block_n, Sink &sink, const uint32_t lane) {
+    typedef typename RingSpan<kSpanBlocks>::cidx_t ring_cidx_t;
+    constexpr uint32_t kRingSpanValues = RingSpan<kSpanBlocks>::kValues;
+    constexpr uint32_t kRingSpanChunks = RingSpan<kSpanBlocks>::kChunks;
+    constexpr uint32_t kRingChunkSlots = RingSpan<kSpanBlocks>::kSlots;
+    ring_cidx_t *const cidx = (ring_cidx_t *)cidx_lds;
     constexpr uint32_t w = (uint32_t)W;
     constexpr uint32_t kLaneRuns = kRingTableRuns - 1;
     const uint8_t *const ring = io.sh.ring;
@@ -915,8 +928,8 @@ __device__ __forceinline__ void ring_expand_span(RingExpander &io, uint2 *tbl, r
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-#if PQ2_RING_SPAN_BLOCKS == 4
             if (!alone) {
+                if constexpr (kSpanBlocks == 4) {
                 // lane l owns the 16 consecutive chunks from 16 l on: four per dword
                 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
                 const u32x4 mm = *(const u32x4 *)&cidx[16u * lane];
@@ -949,9 +962,7 @@ __device__ __forceinline__ void ring_expand_span(RingExpander &io, uint2 *tbl, r
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-            }
-#else
-            if (!alone) {
+            } else {
                 // lane l owns the 8 consecutive chunks from 8 l on: two per dword
                 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
                 u32x4 mm = *(const u32x4 *)&cidx[8u * lane];
@@ -979,15 +990,14 @@ __device__ __forceinline__ void ring_expand_span(RingExpander &io, uint2 *tbl, r
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             }
-
-#endif
+            }
             PQ2_CLOCK_ADD(5, clock_ix);
             const uint64_t clock_p2 = PQ2_CLOCK();
             // ---- phase 2: one chunk per lane and step ---------------------------------------------------
             const uint32_t q_end = (hi + mis + 3u) >> 2;
             const uint32_t q_first = ((lo + mis) >> 2) + lane;
             bool ragged = false;
-            constexpr uint32_t kSteps = 4u * kRingSpanBlocks + 1u;
+            constexpr uint32_t kSteps = 4u * kSpanBlocks + 1u;
 #pragma unroll
             for (uint32_t g0 = 0; g0 < kSteps; g0 += kRingStepGroup) {
                 uint32_t j[kRingStepGroup];
@@ -1228,7 +1238,7 @@ __global__ __launch_bounds__(kRingThreads, PQ2_RING_MIN_WAVES) void ring_kernel(
     }
     const uint32_t e = wave - (wave > walker ? 1u : 0u);
     uint2 *tbl = (uint2 *)tables + e * (kRingTableRuns + 2u);
-    ring_cidx_t *cidx = (ring_cidx_t *)(tables + kRingExpanders * (kRingTableRuns + 2u) * 8u) + e * kRingChunkSlots;
+    uint8_t *const cidx = tables + kRingExpanders * (kRingTableRuns + 2u) * 8u + e * RingSpan<2>::kBytes;
     if (lane < 2) tbl[kRingTableRuns + lane] = make_uint2(kRingNoRun, 0u);  // read by tbl[j + 1] only
 
     RingExpander io;
@@ -1256,14 +1266,16 @@ __global__ __launch_bounds__(kRingThreads, PQ2_RING_MIN_WAVES) void ring_kernel(
         if (ring_tile_wanted(pg, tile_mask, t * kRingTileBlocks / kBlocksPerTile)) {
             const uint32_t tile_first = t * kRingTileValues;
             out_u32 *const out = (out_u32 *)pg.out_addr + tile_first;
-            constexpr uint32_t kSpans = kRingTileBlocks / kRingSpanBlocks;
-            for (uint32_t i = 0; i < kSpans; ++i) {
-                const uint32_t span_first = tile_first + i * kRingSpanValues;
+            // pages of levels: the tile as one span
+            const uint32_t span_blocks = (kWords == 0 && kRingTileBlocks == 4 && w != 0u && w <= kRingWholeTileBits) ? 4u : kRingSpanBlocks;
+            const uint32_t span_values = span_blocks * kBlockValues;
+            for (uint32_t i = 0; i < kRingTileBlocks / span_blocks; ++i) {
+                const uint32_t span_first = tile_first + i * span_values;
                 if (span_first >= n) break;
-                const uint32_t span_n = min(kRingSpanValues, n - span_first);
+                const uint32_t span_n = min(span_values, n - span_first);
                 io.await_start(span_first, lane);
                 if (io.aborted) return;
-                const u32x4 r4 = *(const u32x4 *)&sh.rq[(t * kRingTileBlocks + i * kRingSpanBlocks) & (kRq - 1u)];
+                const u32x4 r4 = *(const u32x4 *)&sh.rq[(t * kRingTileBlocks + i * span_blocks) & (kRq - 1u)];
                 Resume rs;
                 rs.run_index = __builtin_amdgcn_readfirstlane(r4.x);
                 rs.rem_kind = __builtin_amdgcn_readfirstlane(r4.y);
@@ -1272,17 +1284,22 @@ __global__ __launch_bounds__(kRingThreads, PQ2_RING_MIN_WAVES) void ring_kernel(
                 // the lowest byte the span (and everything behind it) can ask for: the group that holds a
                 // bit-packed run's first value here, or the byte behind an RLE run
                 io.raise_need((rs.rem_kind >> 31) == kBitpacked ? rs.payload + (rs.skip >> 3) * w : rs.skip, lane);
-#define PQ2_W(N)                                                                           \
-    case N:                                                                                \
-        ring_expand_span<N>(io, tbl, cidx, rs, end, n, span_first, span_n, sink, lane);    \
+#define PQ2_W(N)                                                                                            \
+    case N:                                                                                                 \
+        ring_expand_span<N, kRingSpanBlocks>(io, tbl, cidx, rs, end, n, span_first, span_n, sink, lane);    \
+        break;
+#define PQ2_W_LEVELS(N)                                                                                                     \
+    case N:                                                                                                                 \
+        ring_expand_span<N, kRingTileBlocks == 4 ? 4 : 2>(io, tbl, cidx, rs, end, n, span_first, span_n, sink, lane);       \
         break;
                 if constexpr (kWords == 0) {
-                    IndexSink sink = {out + i * kRingSpanValues};
+                    IndexSink sink = {out + i * span_values};
+                    static_assert(kRingWholeTileBits <= 2, "the cases below");
                     switch (w) {
 #ifdef PQ2_ONLY_W
                         PQ2_W(PQ2_ONLY_W)
 #else
-                        PQ2_W(1) PQ2_W(2) PQ2_W(3) PQ2_W(4) PQ2_W(5) PQ2_W(6) PQ2_W(7) PQ2_W(8)
+                        PQ2_W_LEVELS(1) PQ2_W_LEVELS(2) PQ2_W(3) PQ2_W(4) PQ2_W(5) PQ2_W(6) PQ2_W(7) PQ2_W(8)
                         PQ2_W(9) PQ2_W(10) PQ2_W(11) PQ2_W(12) PQ2_W(13) PQ2_W(14) PQ2_W(15) PQ2_W(16)
                         PQ2_W(17) PQ2_W(18) PQ2_W(19) PQ2_W(20) PQ2_W(21) PQ2_W(22) PQ2_W(23) PQ2_W(24)
                         PQ2_W(25) PQ2_W(26) PQ2_W(27) PQ2_W(28) PQ2_W(29) PQ2_W(30) PQ2_W(31) PQ2_W(32)
@@ -1307,6 +1324,7 @@ __global__ __launch_bounds__(kRingThreads, PQ2_RING_MIN_WAVES) void ring_kernel(
                     bad_index |= sink.bad;
                 }
 #undef PQ2_W
+#undef PQ2_W_LEVELS
                 if (io.aborted) return;
             }
         }

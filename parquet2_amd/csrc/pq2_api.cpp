@@ -39,6 +39,7 @@ uint32_t pq2_gather_tile_values();
 hipError_t pq2_launch_front(void *streams, const void *raw, uint32_t n_pages, int32_t *front_status, hipStream_t stream);
 hipError_t pq2_launch_select(const void *pieces, uint32_t n_pieces, hipStream_t stream);
 hipError_t pq2_launch_optional(const void *pages, uint32_t n_pages, uint32_t value_words, int32_t *status,
+                               uint32_t seg_rows, uint32_t n_segs, uint32_t *seg_valid,
                                hipStream_t stream);
 hipError_t pq2_launch_bitunpack64(const void *d_packed, uint32_t packed_len, uint32_t num_bits, uint32_t length,
                                   uint64_t *d_out, hipStream_t stream);
@@ -101,8 +102,10 @@ static_assert(sizeof(GatherPage) == 40, "GatherPage layout");
 
 struct OptionalPage {  // must match pq2::OptionalPage
     uint64_t level_addr, idx_addr, out_addr, validity_addr, dict_addr;
-    uint32_t rows, idx_values, dict_len, max_level, idx_status_at, reserved;
+    uint32_t rows, idx_values, dict_len, max_level, idx_status_at, first_seg;
 };
+constexpr uint64_t kOptionalSegRows = 65536;     // batches of few pages: one workgroup of optional_kernel per so many rows
+constexpr uint64_t kOptionalWholePages = 256;    // from this many pages on: one workgroup per page
 static_assert(sizeof(OptionalPage) == 64, "OptionalPage layout");
 
 struct SelectPiece {  // must match pq2::SelectPiece
@@ -167,7 +170,7 @@ struct pq2_ctx {
     uint64_t last_scout_tiles = 0;        // stream tiles of the last batch, if the scout kernels walked it
     bool last_scout = false;
     // pq2_decode_dict_batch_device: the decoded indices, and the per-page gather descriptors (page-locked + device)
-    DevBuf d_indices, d_gather;
+    DevBuf d_indices, d_gather, d_seg_valid;
     void *h_gather = nullptr;
     size_t h_gather_cap = 0;
     hipEvent_t gather_copied = nullptr;
@@ -616,7 +619,7 @@ int32_t pq2_ctx_destroy(pq2_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     for (DevBuf *b : {&ctx->d_meta, &ctx->d_status, &ctx->d_resume, &ctx->d_tile_page, &ctx->d_run_pos, &ctx->d_state,
-                      &ctx->d_tickets, &ctx->d_scout_table, &ctx->d_scout_words, &ctx->d_indices, &ctx->d_gather, &ctx->d_in, &ctx->d_out})
+                      &ctx->d_tickets, &ctx->d_scout_table, &ctx->d_scout_words, &ctx->d_seg_valid, &ctx->d_indices, &ctx->d_gather, &ctx->d_in, &ctx->d_out})
         if (b->ptr) (void)hipFree(b->ptr);
     for (hipStream_t s : {ctx->parse_stream, ctx->expand_stream[0], ctx->expand_stream[1]})
         if (s) (void)hipStreamDestroy(s);
@@ -831,6 +834,14 @@ int32_t pq2_decode_optional_dict_batch_device(pq2_ctx *ctx, const void *d_in, ui
         const size_t bytes = n_pages * sizeof(OptionalPage);
         if ((st = stage_block(ctx, bytes, bytes))) return st;
         OptionalPage *g = static_cast<OptionalPage *>(ctx->h_gather);
+        // few pages: every page in segments, so that large pages are shared out over the GPU
+        static const long long seg_knob = [] {  // PQ2_OPTIONAL_SEG_ROWS: 0 = always whole pages, n = segments of n * 4096 rows
+            const char *v = std::getenv("PQ2_OPTIONAL_SEG_ROWS");
+            return v ? std::atoll(v) : -1ll;
+        }();
+        const uint64_t seg_rows = seg_knob == 0 ? 0 : seg_knob > 0 ? uint64_t(seg_knob) * 4096
+                                  : n_pages >= kOptionalWholePages ? 0 : kOptionalSegRows;
+        uint64_t n_segs = 0;
         for (uint64_t i = 0; i < n_pages; ++i) {
             const bool skip = ctx->host_status[i] != PQ2_OK || ctx->host_status[n_pages + i] != PQ2_OK;
             g[i].level_addr = reinterpret_cast<uint64_t>(d_scratch + both[i].out_off);
@@ -843,11 +854,16 @@ int32_t pq2_decode_optional_dict_batch_device(pq2_ctx *ctx, const void *d_in, ui
             g[i].dict_len = dicts[i].dict_len;
             g[i].max_level = max_def_levels[i];
             g[i].idx_status_at = static_cast<uint32_t>(n_pages + i);
-            g[i].reserved = 0;
+            g[i].first_seg = static_cast<uint32_t>(n_segs);
+            if (seg_rows) n_segs += std::max<uint64_t>(1, (uint64_t(g[i].rows) + seg_rows - 1) / seg_rows);
         }
+        if (n_segs > 0x7fffffffull) return fail(ctx, PQ2_INVALID_PARAMETER, "batch too large for one launch");
+        if (seg_rows && (st = reserve(ctx, ctx->d_seg_valid, n_segs * sizeof(uint32_t)))) return st;
         if ((st = upload_block(ctx, bytes, stream))) return st;
         PQ2_HIP(ctx, pq2_launch_optional(ctx->d_gather.ptr, static_cast<uint32_t>(n_pages), value_size / 4,
-                                         static_cast<int32_t *>(ctx->d_status.ptr), stream));
+                                         static_cast<int32_t *>(ctx->d_status.ptr), static_cast<uint32_t>(seg_rows),
+                                         static_cast<uint32_t>(n_segs), static_cast<uint32_t *>(ctx->d_seg_valid.ptr),
+                                         stream));
         // from here on the batch has n_pages statuses: a page's own, or else its index stream's
         for (uint64_t i = 0; i < n_pages; ++i)
             if (ctx->host_status[i] == PQ2_OK) ctx->host_status[i] = ctx->host_status[n_pages + i];

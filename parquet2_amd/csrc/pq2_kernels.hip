@@ -1082,18 +1082,73 @@ struct OptionalPage {  // must match the host's
     uint64_t out_addr, validity_addr, dict_addr;
     uint32_t rows, idx_values, dict_len, max_level;
     uint32_t idx_status_at;  // where the index stream's status lies in the status array
-    uint32_t reserved;
+    uint32_t first_seg;      // batch-wide number of the page's first segment of `seg_rows` rows
 };
 
+// Which page segment `seg` belongs to: the last one whose first segment is not behind it (pages without rows share
+// their successor's).
+__device__ __forceinline__ uint32_t optional_page_of(const OptionalPage *__restrict__ pages, uint32_t n_pages, uint32_t seg) {
+    uint32_t lo = 0, hi = n_pages;
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (pages[mid].first_seg <= seg) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// A batch of few pages is cut into segments of `seg_rows` rows (a multiple of 4096), one workgroup each, so that a
+// few large pages still fill the GPU.  A segment has to know how many valid rows lie before it in its page: this
+// kernel counts the valid rows of every segment.  The workgroup of a page's first segment also takes over the index
+// stream's status where the page's own is 0 (before any lookup can report an index out of range).
+__global__ __launch_bounds__(256) void optional_count_kernel(const OptionalPage *__restrict__ pages, uint32_t n_pages,
+                                                             uint32_t seg_rows, uint32_t *__restrict__ seg_valid,
+                                                             int32_t *__restrict__ status) {
+    __shared__ uint32_t wave_sum[4];
+    const uint32_t seg = blockIdx.x;
+    const uint32_t page = optional_page_of(pages, n_pages, seg);
+    const OptionalPage pg = pages[page];
+    const uint32_t first = (seg - pg.first_seg) * seg_rows;
+    if (first == 0u && threadIdx.x == 0 && status[page] == 0) status[page] = status[pg.idx_status_at];
+    if (first >= pg.rows) {  // (a page without rows has one segment all the same)
+        if (threadIdx.x == 0) seg_valid[seg] = 0u;
+        return;
+    }
+    typedef __attribute__((address_space(1))) const uint32_t gu32;
+    typedef __attribute__((address_space(1))) const u32x4 gu32x4;
+    gu32 *const level = (gu32 *)pg.level_addr;  // 16-byte aligned
+    const uint32_t last = min(pg.rows, first + seg_rows);
+    uint32_t count = 0;
+    for (uint32_t r = first + 4u * threadIdx.x; r < last; r += 1024u) {
+        if (r + 3u < last) {
+            const u32x4 lv = ((gu32x4 *)level)[r >> 2];
+            count += (lv.x == pg.max_level) + (lv.y == pg.max_level) + (lv.z == pg.max_level) + (lv.w == pg.max_level);
+        } else {
+            for (uint32_t k = r; k < last; ++k) count += level[k] == pg.max_level;
+        }
+    }
+    count = wave_inclusive_sum(count);
+    if ((threadIdx.x & 63u) == 63u) wave_sum[threadIdx.x >> 6] = count;
+    __syncthreads();
+    if (threadIdx.x == 0) seg_valid[seg] = wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
+}
+
+// seg_rows = 0: one workgroup per page (blockIdx.x = page); else one per segment of seg_rows rows, `seg_valid` from
+// optional_count_kernel.
 template <int kWords>
 __global__ __launch_bounds__(256) void optional_kernel(const OptionalPage *__restrict__ pages, uint32_t n_pages,
-                                                       int32_t *__restrict__ status) {
+                                                       int32_t *__restrict__ status, uint32_t seg_rows,
+                                                       const uint32_t *__restrict__ seg_valid) {
     constexpr uint32_t kQuads = 4;                    // quads of rows per thread and step
     constexpr uint32_t kStepRows = 1024u * kQuads;    // rows of a page per step: quad q of thread t = rows q * 1024 + 4 t ...
     __shared__ uint32_t wave_total[2][kQuads][4];
-    const uint32_t page = blockIdx.x;
+    __shared__ uint32_t valid_before;
+    const uint32_t page = seg_rows == 0u ? blockIdx.x : optional_page_of(pages, n_pages, blockIdx.x);
     if (page >= n_pages) return;
     const OptionalPage pg = pages[page];
+    // the rows of this workgroup: [row_first, row_last)
+    const uint32_t row_first = seg_rows == 0u ? 0u : (blockIdx.x - pg.first_seg) * seg_rows;
+    if (seg_rows != 0u && row_first >= pg.rows) return;
+    const uint32_t row_last = seg_rows == 0u ? pg.rows : min(pg.rows, row_first + seg_rows);
     typedef __attribute__((address_space(1))) const uint32_t gu32;
     typedef __attribute__((address_space(1))) const u32x4 gu32x4;
     gu32 *const level = (gu32 *)pg.level_addr;
@@ -1104,6 +1159,15 @@ __global__ __launch_bounds__(256) void optional_kernel(const OptionalPage *__res
         (__attribute__((address_space(1))) uint8_t *)pg.validity_addr;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     uint32_t used = 0;  // valid rows before this step = indices consumed
+    if (seg_rows != 0u && row_first != 0u) {  // those of the page's segments before this one
+        if (threadIdx.x == 0) {
+            uint32_t sum = 0;
+            for (uint32_t sg = pg.first_seg; sg < blockIdx.x; ++sg) sum += seg_valid[sg];
+            valid_before = sum;
+        }
+        __syncthreads();
+        used = valid_before;
+    }
     bool bad = false;
     uint32_t flip = 0;
     // the four levels of rows r0 .. r0 + 3 (rows behind the page's end: a level that is not the maximum)
@@ -1122,8 +1186,8 @@ __global__ __launch_bounds__(256) void optional_kernel(const OptionalPage *__res
     const bool aligned = ((pg.out_addr & 15u) | (pg.validity_addr & 3u)) == 0u;
     u32x4 lv_next[kQuads];
 #pragma unroll
-    for (uint32_t q = 0; q < kQuads; ++q) lv_next[q] = load_levels(q * 1024u + 4u * threadIdx.x);
-    for (uint32_t base = 0; base < pg.rows; base += kStepRows, flip ^= 1u) {
+    for (uint32_t q = 0; q < kQuads; ++q) lv_next[q] = load_levels(row_first + q * 1024u + 4u * threadIdx.x);
+    for (uint32_t base = row_first; base < row_last; base += kStepRows, flip ^= 1u) {
         uint32_t r0[kQuads], c[kQuads], incl[kQuads];
         bool v[kQuads][4];
 #pragma unroll
@@ -1207,6 +1271,10 @@ __global__ __launch_bounds__(256) void optional_kernel(const OptionalPage *__res
         }
     }
     const int any_bad = __syncthreads_or(bad ? 1 : 0);
+    if (seg_rows != 0u) {  // (optional_count_kernel has merged the index stream's status)
+        if (threadIdx.x == 0 && any_bad) atomicCAS(&status[page], 0, 1);  // PQ2_OUT_OF_SPEC
+        return;
+    }
     if (threadIdx.x == 0 && status[page] == 0) {
         const int32_t of_indices = status[pg.idx_status_at];
         status[page] = of_indices != 0 ? of_indices : (any_bad ? 1 : 0);  // PQ2_OUT_OF_SPEC
@@ -1889,16 +1957,22 @@ extern "C" hipError_t pq2_launch_decode(const void *pages, uint32_t n_pages, voi
     return hipGetLastError();
 }
 
+// seg_rows = 0: one workgroup per page.  Else the pages are cut into `n_segs` segments of seg_rows rows
+// (OptionalPage::first_seg) and `seg_valid` has room for n_segs words.
 extern "C" hipError_t pq2_launch_optional(const void *pages, uint32_t n_pages, uint32_t value_words, int32_t *status,
-                                          hipStream_t stream) {
+                                          uint32_t seg_rows, uint32_t n_segs, uint32_t *seg_valid, hipStream_t stream) {
     if (n_pages == 0) return hipSuccess;
     const pq2::OptionalPage *p = (const pq2::OptionalPage *)pages;
+    const uint32_t grid = seg_rows == 0u ? n_pages : n_segs;
+    if (grid == 0u) return hipSuccess;
+    if (seg_rows != 0u)
+        hipLaunchKernelGGL(pq2::optional_count_kernel, dim3(grid), dim3(256), 0, stream, p, n_pages, seg_rows, seg_valid, status);
     if (value_words == 1)
-        hipLaunchKernelGGL(pq2::optional_kernel<1>, dim3(n_pages), dim3(256), 0, stream, p, n_pages, status);
+        hipLaunchKernelGGL(pq2::optional_kernel<1>, dim3(grid), dim3(256), 0, stream, p, n_pages, status, seg_rows, seg_valid);
     else if (value_words == 2)
-        hipLaunchKernelGGL(pq2::optional_kernel<2>, dim3(n_pages), dim3(256), 0, stream, p, n_pages, status);
+        hipLaunchKernelGGL(pq2::optional_kernel<2>, dim3(grid), dim3(256), 0, stream, p, n_pages, status, seg_rows, seg_valid);
     else
-        hipLaunchKernelGGL(pq2::optional_kernel<3>, dim3(n_pages), dim3(256), 0, stream, p, n_pages, status);
+        hipLaunchKernelGGL(pq2::optional_kernel<3>, dim3(grid), dim3(256), 0, stream, p, n_pages, status, seg_rows, seg_valid);
     return hipGetLastError();
 }
 

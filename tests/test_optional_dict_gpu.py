@@ -117,6 +117,65 @@ def test_nullable_pages_match_the_consumer_loop(ctx, oracle, value_size):
     assert 0.02 < 1.0 - validity[:65536].mean() < 0.08  # the 5 % nulls of the definition-level pages
 
 
+def test_large_pages_in_segments(ctx, oracle):
+    """Few large pages: the rows of a page are shared out over workgroups of 65 536 rows each, which have to agree
+    on how many valid rows lie before them.  Pages that end inside a segment, a page of exactly two segments, a
+    dictionary that misses an index only a row of a late segment consumes, an index stream that is too short."""
+    rng = np.random.default_rng(77)
+    table = rng.integers(0, 1 << 32, size=(1 << 9, 2), dtype=np.uint64).astype(np.uint32)
+    b = Batch()
+    pages = []
+    shapes = [(1, 700001, None, 512), (1, 131072, None, 512), (3, 300000, None, 512), (1, 400000, 150000, 512),
+              (1, 262145, None, 512)]
+    for p, (max_level, rows, idx_values, dict_len) in enumerate(shapes):
+        if max_level == 1:
+            def_stream, _ = synth.def_levels_page(synth.seed_for(3, 120 + p), rows)
+        else:
+            lv = np.repeat(rng.integers(0, max_level + 1, size=rows // 5 + 1), 5)[:rows].astype(np.uint32)
+            def_stream = np.frombuffer(encode_u32(lv, get_bit_width(max_level)), dtype=np.uint8)
+        idx_stream, idx = synth.dict_page(synth.seed_for(2, 130 + p), rows, 9, 12.0, 50.0)
+        if p == 4:  # the largest index sits where only the page's last segment gets to it
+            idx = idx.copy()
+            idx[idx == idx.max()] = 0
+            idx[245000] = 511
+            idx_stream = synth.encode_hybrid(idx, 9)
+            dict_len = 511
+        args = (def_stream, max_level, rows, idx_stream, 9, rows if idx_values is None else idx_values)
+        b.add(*args, (0, dict_len, 0), gap=p % 3)
+        pages.append((args, dict_len))
+    got, validity, status = b.run(ctx, table.view(np.uint8).reshape(-1), 8)
+    covered = np.zeros(b.rows, dtype=bool)
+    for k, (d, (args, dict_len)) in enumerate(zip(b.defs, pages)):
+        out, present, bad = expected(oracle, *args, table[:dict_len])
+        o, rows = d[4], d[3]
+        assert status[k] == (OUT_OF_SPEC if bad else OK), k
+        assert (validity[o:o + rows] == present).all() and (got[o:o + rows] == out).all(), k
+        covered[o:o + rows] = True
+    assert status[4] == OUT_OF_SPEC
+    assert (got[~covered] == 0x5A5A5A5A).all() and (validity[~covered] == 7).all()
+
+
+def test_many_pages_one_workgroup_each(ctx, oracle):
+    """300 pages: one workgroup per page (no segments)."""
+    rng = np.random.default_rng(78)
+    table = rng.integers(0, 1 << 32, size=(1 << 8, 1), dtype=np.uint64).astype(np.uint32)
+    b = Batch()
+    pages = []
+    for p in range(300):
+        rows = int(rng.integers(1, 20000))
+        def_stream, _ = synth.def_levels_page(synth.seed_for(3, 200 + p), rows, 50.0, 5.0)
+        idx_stream, _ = synth.dict_page(synth.seed_for(2, 500 + p), rows, 8, 6.0, 20.0)
+        args = (def_stream, 1, rows, idx_stream, 8, rows)
+        b.add(*args, (0, 256, 0), gap=p % 2)
+        pages.append(args)
+    got, validity, status = b.run(ctx, table.view(np.uint8).reshape(-1), 4)
+    assert (status == OK).all()
+    for d, args in zip(b.defs, pages):
+        out, present, bad = expected(oracle, *args, table)
+        o, rows = d[4], d[3]
+        assert (validity[o:o + rows] == present).all() and (got[o:o + rows] == out).all()
+
+
 def test_statuses(ctx, oracle):
     rows = 20000
     table = (np.arange(256, dtype=np.uint32) * 5 + 2).reshape(-1, 1)

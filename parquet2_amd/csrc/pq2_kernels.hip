@@ -960,19 +960,56 @@ __global__ __launch_bounds__(256, 4) void decode_kernel(const PageDev *__restric
 // bitunpack_kernel: `length` values of width w from a bit-packed buffer
 // (bitpacked::Decoder<u32>, src/encoding/bitpacked/decode.rs:28-86).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bitunpack_kernel(uint64_t in_addr, uint32_t in_len, uint32_t w,
-                                                        uint32_t length, uint32_t *__restrict__ out) {
+// A wave takes the values in blocks of 2048: the 256 W bytes of a block (they begin at a whole byte) come into the
+// wave's LDS with coalesced dwordx4 loads that are all in flight together -- every packed byte is requested once,
+// whatever the width -- and every lane then takes 4 values per step out of LDS (fields4_at) and stores one dwordx4:
+// 1 KiB of contiguous output per wave instruction.  A last block that is not full, and an output that is not
+// 16-byte aligned, go value group by value group straight from memory (emit_bp).
+constexpr uint32_t kUnpackBlock = 2048;
+__host__ __device__ constexpr uint32_t unpack_pieces(uint32_t w) { return 16u * w + 2u; }  // of 16 bytes: the block, its misalignment, 8 bytes of slack
+template <int W>
+__device__ __forceinline__ void unpack_block_lds(const __amdgpu_buffer_rsrc_t rsrc, const uint32_t a, uint8_t *lds,
+                                                 out_u32 *out, const uint32_t lane) {
+    constexpr uint32_t kPieces = unpack_pieces((uint32_t)W);
+    constexpr uint32_t kRounds = (kPieces + 63u) / 64u;
+    const uint32_t a0 = a & ~15u;
+    u32x4 v[kRounds];
+#pragma unroll
+    for (uint32_t i = 0; i < kRounds; ++i)
+        if (lane + 64u * i < kPieces) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, a0 + (lane + 64u * i) * 16u, 0, 0);
+#pragma unroll
+    for (uint32_t i = 0; i < kRounds; ++i)
+        if (lane + 64u * i < kPieces) *(u32x4 *)(lds + (lane + 64u * i) * 16u) = v[i];
+    wave_sync();
+    const uint32_t bit0 = (a - a0) * 8u;
+#pragma unroll 2
+    for (uint32_t s = 0; s < kUnpackBlock / 256u; ++s) {
+        const uint32_t p = (s * 64u + lane) * 4u;
+        store4(fields4_at<W>(lds, bit0 + p * (uint32_t)W), out + p);
+    }
+    wave_sync();  // the next block's bytes come into the same LDS
+}
+
+template <int W>
+__global__ __launch_bounds__(256, 6) void bitunpack_kernel(uint64_t in_addr, uint32_t in_len, uint32_t length,
+                                                           uint32_t *__restrict__ out, uint32_t wave_lds) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t unpack_lds[];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t delta = (uint32_t)(in_addr & 15u);
     const uint32_t end = delta + in_len;
     const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(in_addr - delta, (end + 3u) & ~3u);
-    const uint32_t n_blocks = (length + kBlockValues - 1) / kBlockValues;
-    for (uint32_t block = blockIdx.x * kBlocksPerTile + wave; block < n_blocks;
-         block += gridDim.x * kBlocksPerTile) {
-        const uint32_t start = block * kBlockValues;
-        const uint32_t cnt = min(kBlockValues, length - start);
-        emit_bp_dispatch(w, rsrc, delta, start, (out_u32 *)(out + start), cnt, lane);
+    const uint32_t n_blocks = (length + kUnpackBlock - 1) / kUnpackBlock;
+    const bool aligned = ((uintptr_t)out & 15u) == 0u;
+    uint8_t *const lds = unpack_lds + wave * wave_lds;
+    for (uint32_t block = blockIdx.x * 4u + wave; block < n_blocks; block += gridDim.x * 4u) {
+        const uint32_t start = block * kUnpackBlock;
+        const uint32_t cnt = min(kUnpackBlock, length - start);
+        out_u32 *const o = (out_u32 *)(out + start);
+        if (cnt < kUnpackBlock || !aligned)
+            emit_bp<W>(rsrc, delta, start, o, cnt, lane);
+        else
+            unpack_block_lds<W>(rsrc, delta + block * (kUnpackBlock / 8u) * (uint32_t)W, lds, o, lane);
     }
 }
 
@@ -2036,9 +2073,22 @@ extern "C" hipError_t pq2_launch_gather(const void *pages, uint32_t n_pages, uin
 extern "C" hipError_t pq2_launch_bitunpack(const void *d_packed, uint32_t packed_len, uint32_t num_bits,
                                            uint32_t length, uint32_t *d_out, hipStream_t stream) {
     if (length == 0) return hipSuccess;
-    const uint32_t n_tiles = (length + pq2::kTileValues - 1) / pq2::kTileValues;
-    const uint32_t grid = n_tiles < 16384u ? n_tiles : 16384u;
-    hipLaunchKernelGGL(pq2::bitunpack_kernel, dim3(grid), dim3(256), 0, stream, (uint64_t)(uintptr_t)d_packed,
-                       packed_len, num_bits, length, d_out);
+    const uint32_t n_groups = (length + 4u * pq2::kUnpackBlock - 1) / (4u * pq2::kUnpackBlock);  // of four blocks: a workgroup's turn
+    const uint32_t grid = n_groups < 16384u ? n_groups : 16384u;
+    const uint32_t wave_lds = (pq2::unpack_pieces(num_bits ? num_bits : 1u) * 16u + 63u) & ~63u;
+    switch (num_bits) {
+#define PQ2_W(N)                                                                                                      \
+    case N:                                                                                                           \
+        hipLaunchKernelGGL(pq2::bitunpack_kernel<N>, dim3(grid), dim3(256), 4u * wave_lds, stream,                    \
+                           (uint64_t)(uintptr_t)d_packed, packed_len, length, d_out, wave_lds);                       \
+        break;
+        PQ2_W(1) PQ2_W(2) PQ2_W(3) PQ2_W(4) PQ2_W(5) PQ2_W(6) PQ2_W(7) PQ2_W(8)
+        PQ2_W(9) PQ2_W(10) PQ2_W(11) PQ2_W(12) PQ2_W(13) PQ2_W(14) PQ2_W(15) PQ2_W(16)
+        PQ2_W(17) PQ2_W(18) PQ2_W(19) PQ2_W(20) PQ2_W(21) PQ2_W(22) PQ2_W(23) PQ2_W(24)
+        PQ2_W(25) PQ2_W(26) PQ2_W(27) PQ2_W(28) PQ2_W(29) PQ2_W(30) PQ2_W(31) PQ2_W(32)
+#undef PQ2_W
+        default:
+            return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }

@@ -110,7 +110,7 @@ constexpr uint32_t kRingAllParsed = 0xffffffffu;
 #ifdef PQ2_RING_TIMING  // diagnostic build: shader clocks spent per role and wait, summed over all waves
 // 0 walk total, 1 walk waiting for room, 2 walk waiting for fills, 3 walk chase, 4 walk after its last publish,
 // 8 expand total, 9 waiting for a block start, 10 waiting for runs, 11 waiting for bytes
-__device__ unsigned long long g_ring_clocks[32];  // 16..: event counts of the walk (see PQ2_COUNT uses)
+static __device__ unsigned long long g_ring_clocks[32];  // 16..: event counts of the walk (see PQ2_COUNT uses)
 #define PQ2_CLOCK() __builtin_amdgcn_s_memtime()
 #define PQ2_CLOCK_ADD(SLOT, T0) clocks[(SLOT) & 7] += __builtin_amdgcn_s_memtime() - (T0)
 #define PQ2_COUNT(SLOT, V) counts[SLOT] += (V)

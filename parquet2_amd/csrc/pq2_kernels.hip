@@ -1411,25 +1411,77 @@ __global__ __launch_bounds__(256) void front_kernel(PageDev *__restrict__ stream
 // ---------------------------------------------------------------------------
 // bitunpack64_kernel: `length` values of width w (1..64) from a bit-packed
 // buffer into u64 (bitpacked::Decoder<u64>, decode.rs:28-86; unpack64,
-// unpack.rs:21-95: LSB-first fields of a little-endian byte stream).  One value
-// per thread and step: three aligned dwords, two funnel shifts, a mask.
+// unpack.rs:21-95: LSB-first fields of a little-endian byte stream).  As
+// bitunpack_kernel: a wave takes blocks of 1024 values, whose 128 w bytes come
+// into its LDS with coalesced dwordx4 loads that are all in flight together;
+// every lane then takes two values per step out of LDS (three aligned dwords,
+// two funnel shifts, a mask each) and stores them as one dwordx4.  A last block
+// that is not full, and an output that is not 16-byte aligned, go one value per
+// lane straight from memory.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bitunpack64_kernel(uint64_t in_addr, uint32_t in_len, uint32_t w,
-                                                          uint32_t length, uint64_t *__restrict__ out) {
+constexpr uint32_t kUnpack64Block = 1024;
+__host__ __device__ constexpr uint32_t unpack64_pieces(uint32_t w) { return 8u * w + 2u; }  // of 16 bytes: the block, its misalignment, slack
+constexpr uint32_t kUnpack64Rounds = (unpack64_pieces(64u) + 63u) / 64u;
+
+__device__ __forceinline__ uint64_t field64(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t sh, uint64_t mask) {
+    const uint32_t lo = __builtin_amdgcn_alignbit(x1, x0, sh);
+    const uint32_t hi = __builtin_amdgcn_alignbit(x2, x1, sh);
+    return (((uint64_t)hi << 32) | lo) & mask;
+}
+
+__global__ __launch_bounds__(256, 6) void bitunpack64_kernel(uint64_t in_addr, uint32_t in_len, uint32_t w,
+                                                             uint32_t length, uint64_t *__restrict__ out,
+                                                             uint32_t wave_lds) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t unpack64_lds[];
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u;
     const uint32_t delta = (uint32_t)(in_addr & 15u);
     const uint32_t end = delta + in_len;
     const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(in_addr - delta, (end + 3u) & ~3u);
     const uint64_t mask = w == 64u ? ~0ull : ((1ull << w) - 1ull);
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < length; i += gridDim.x * 256u) {
-        const uint64_t bit = (uint64_t)delta * 8u + (uint64_t)i * w;
-        const uint32_t d = (uint32_t)(bit >> 5) * 4u;  // byte offset of the first dword (the buffer is < 4 GiB)
-        const uint32_t sh = (uint32_t)bit & 31u;
-        const uint32_t x0 = __builtin_amdgcn_raw_buffer_load_b32(rsrc, d, 0, 0);
-        const uint32_t x1 = __builtin_amdgcn_raw_buffer_load_b32(rsrc, d + 4u, 0, 0);
-        const uint32_t x2 = __builtin_amdgcn_raw_buffer_load_b32(rsrc, d + 8u, 0, 0);
-        const uint32_t lo = __builtin_amdgcn_alignbit(x1, x0, sh);
-        const uint32_t hi = __builtin_amdgcn_alignbit(x2, x1, sh);
-        out[i] = (((uint64_t)hi << 32) | lo) & mask;
+    const uint32_t n_blocks = (length + kUnpack64Block - 1u) / kUnpack64Block;
+    const bool aligned = ((uintptr_t)out & 15u) == 0u;
+    uint8_t *const lds = unpack64_lds + wave * wave_lds;
+    const uint32_t pieces = unpack64_pieces(w);
+    for (uint32_t block = blockIdx.x * 4u + wave; block < n_blocks; block += gridDim.x * 4u) {
+        const uint32_t start = block * kUnpack64Block;
+        const uint32_t cnt = min(kUnpack64Block, length - start);
+        if (cnt < kUnpack64Block || !aligned) {
+            for (uint32_t i = start + lane; i < start + cnt; i += 64u) {
+                const uint64_t bit = (uint64_t)delta * 8u + (uint64_t)i * w;
+                const uint32_t d = (uint32_t)(bit >> 5) * 4u;  // byte offset of the first dword (the buffer is < 4 GiB)
+                out[i] = field64(__builtin_amdgcn_raw_buffer_load_b32(rsrc, d, 0, 0),
+                                 __builtin_amdgcn_raw_buffer_load_b32(rsrc, d + 4u, 0, 0),
+                                 __builtin_amdgcn_raw_buffer_load_b32(rsrc, d + 8u, 0, 0), (uint32_t)bit & 31u, mask);
+            }
+            continue;
+        }
+        const uint32_t a = delta + block * (kUnpack64Block / 8u) * w;  // the block's first byte
+        const uint32_t a0 = a & ~15u;
+        u32x4 v[kUnpack64Rounds];
+#pragma unroll
+        for (uint32_t i = 0; i < kUnpack64Rounds; ++i)
+            if (lane + 64u * i < pieces) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, a0 + (lane + 64u * i) * 16u, 0, 0);
+#pragma unroll
+        for (uint32_t i = 0; i < kUnpack64Rounds; ++i)
+            if (lane + 64u * i < pieces) *(u32x4 *)(lds + (lane + 64u * i) * 16u) = v[i];
+        wave_sync();
+        const uint32_t bit0 = (a - a0) * 8u;
+        typedef __attribute__((address_space(1))) u32x4 g_u32x4;
+#pragma unroll 2
+        for (uint32_t s = 0; s < kUnpack64Block / 128u; ++s) {
+            const uint32_t p = (s * 64u + lane) * 2u;
+            uint64_t f[2];
+#pragma unroll
+            for (uint32_t k = 0; k < 2u; ++k) {
+                const uint32_t bit = bit0 + (p + k) * w;
+                const uint32_t *src = (const uint32_t *)(lds + ((bit >> 3) & ~3u));
+                f[k] = field64(src[0], src[1], src[2], bit & 31u, mask);
+            }
+            const u32x4 o = {(uint32_t)f[0], (uint32_t)(f[0] >> 32), (uint32_t)f[1], (uint32_t)(f[1] >> 32)};
+            *(g_u32x4 *)(out + start + p) = o;
+        }
+        wave_sync();  // the next block's bytes come into the same LDS
     }
 }
 
@@ -2030,9 +2082,10 @@ extern "C" hipError_t pq2_launch_front(void *streams, const void *raw, uint32_t 
 extern "C" hipError_t pq2_launch_bitunpack64(const void *d_packed, uint32_t packed_len, uint32_t num_bits,
                                              uint32_t length, uint64_t *d_out, hipStream_t stream) {
     if (length == 0) return hipSuccess;
-    const uint32_t blocks = (length + 255u) / 256u;
-    hipLaunchKernelGGL(pq2::bitunpack64_kernel, dim3(blocks < 65536u ? blocks : 65536u), dim3(256), 0, stream,
-                       (uint64_t)(uintptr_t)d_packed, packed_len, num_bits, length, d_out);
+    const uint32_t groups = (length + 4u * pq2::kUnpack64Block - 1u) / (4u * pq2::kUnpack64Block);  // of four blocks: a workgroup's turn
+    const uint32_t wave_lds = (pq2::unpack64_pieces(num_bits ? num_bits : 1u) * 16u + 63u) & ~63u;
+    hipLaunchKernelGGL(pq2::bitunpack64_kernel, dim3(groups < 65536u ? groups : 65536u), dim3(256), 4u * wave_lds, stream,
+                       (uint64_t)(uintptr_t)d_packed, packed_len, num_bits, length, d_out, wave_lds);
     return hipGetLastError();
 }
 

@@ -540,6 +540,7 @@ __device__ __forceinline__ void expand_block(const __amdgpu_buffer_rsrc_t rsrc, 
             constexpr uint32_t kSteps = 4u * kSpanBlocks + 1u;
 #pragma unroll
             for (uint32_t g0 = 0; g0 < kSteps; g0 += kStepGroup) {
+                if (((lo + mis) >> 2) + 64u * g0 >= q_end) break;  // a pass of few short runs ends early
                 uint32_t j[kStepGroup];
 #pragma unroll
                 for (uint32_t i = 0; i < kStepGroup; ++i)

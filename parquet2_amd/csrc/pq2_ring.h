@@ -1000,6 +1000,7 @@ __device__ __forceinline__ void ring_expand_span(RingExpander &io, uint2 *tbl, v
             constexpr uint32_t kSteps = 4u * kSpanBlocks + 1u;
 #pragma unroll
             for (uint32_t g0 = 0; g0 < kSteps; g0 += kRingStepGroup) {
+                if (((lo + mis) >> 2) + 64u * g0 >= q_end) break;  // a pass of few short runs ends early
                 uint32_t j[kRingStepGroup];
 #pragma unroll
                 for (uint32_t i = 0; i < kRingStepGroup; ++i)

@@ -260,6 +260,31 @@ int32_t pq2_decode_selected_batch_device(pq2_ctx *ctx, const void *d_in, uint64_
                                          const uint64_t *interval_offsets, uint32_t *d_out, uint64_t out_values,
                                          int32_t *status, void *stream);
 
+/* FilteredHybridBitmapIter::new(HybridDecoderBitmapIter::new(..), selected_rows)
+ * (src/deserialize/filtered_rle.rs:53-274, :8-10) for a batch of pages: the
+ * definition levels of optional flat columns (bit width 1: descs[i].num_bits
+ * must be 1) intersected with the selected row intervals.  What the iterator
+ * hands a reader run by run comes out whole:
+ *   d_validity  one byte per selected row (1: the row holds a value), the rows of
+ *               page i's intervals one after the other from
+ *               d_validity[descs[i].out_off] on -- the bits of its Bitmap and
+ *               Repeated items;
+ *   d_counts    two words per interval, in the order of `intervals`:
+ *               d_counts[2k] = valid rows between the end of the interval before
+ *               (the page's first row for a page's first interval) and interval
+ *               k's first row -- the sum of the Skipped(set_count) items in
+ *               front of it, i.e. how many values the page's value decoder has
+ *               to pass over; d_counts[2k + 1] = valid rows inside interval k.
+ * Rows behind a page's last interval are not looked at, as the iterator ends
+ * there.  Where a level stream holds fewer rows than its page, the reference's
+ * iterator ends with the stream's last run; here the missing rows are null
+ * rows (the zeros HybridRleDecoder pads with, mod.rs:95).  Intervals as for pq2_decode_selected_batch_device.  status[i]: the
+ * level stream's status. */
+int32_t pq2_filtered_validity_batch_device(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const pq2_page_desc *descs,
+                                           uint64_t n_pages, const pq2_interval *intervals,
+                                           const uint64_t *interval_offsets, uint8_t *d_validity, uint64_t validity_rows,
+                                           uint32_t *d_counts, int32_t *status, void *stream);
+
 /* ---- whole V1 data pages, split on the device -------------------------------- */
 
 /* A decompressed DataPage V1 buffer that lies in device memory (for instance

@@ -84,6 +84,9 @@ SIGNATURES = {
                                                            C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p,
                                                            C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
                                                            C.c_void_p]),
+    "pq2_filtered_validity_batch_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+                                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
+                                                       C.c_void_p, C.c_void_p]),
     "pq2_decode_selected_batch_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
                                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
                                                       C.c_void_p]),
@@ -261,6 +264,22 @@ class Context:
                                                     ptr(intervals), ptr(interval_offsets), C.c_void_p(d_out_ptr),
                                                     out_values, ptr(status) if want_status else None,
                                                     C.c_void_p(stream))
+        self._check(st)
+        return status
+
+    def filtered_validity_batch_device(self, d_in_ptr, in_bytes, descs, intervals, interval_offsets, d_validity_ptr,
+                                       validity_rows, d_counts_ptr, stream=0):
+        """FilteredHybridBitmapIter over every page's definition levels (pq2_filtered_validity_batch_device): validity
+        bytes of the selected rows, and per interval the valid rows skipped in front of it and inside it."""
+        descs = np.ascontiguousarray(descs, dtype=PAGE_DESC_DTYPE)
+        intervals = np.ascontiguousarray(intervals, dtype=INTERVAL_DTYPE)
+        interval_offsets = np.ascontiguousarray(interval_offsets, dtype=np.uint64)
+        assert len(interval_offsets) == len(descs) + 1
+        status = np.zeros(len(descs), dtype=np.int32)
+        st = lib().pq2_filtered_validity_batch_device(self._h, C.c_void_p(d_in_ptr), in_bytes, ptr(descs), len(descs),
+                                                      ptr(intervals), ptr(interval_offsets), C.c_void_p(d_validity_ptr),
+                                                      validity_rows, C.c_void_p(d_counts_ptr), ptr(status),
+                                                      C.c_void_p(stream))
         self._check(st)
         return status
 

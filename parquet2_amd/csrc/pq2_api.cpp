@@ -38,6 +38,7 @@ hipError_t pq2_launch_gather(const void *pages, uint32_t n_pages, uint32_t n_til
 uint32_t pq2_gather_tile_values();
 hipError_t pq2_launch_front(void *streams, const void *raw, uint32_t n_pages, int32_t *front_status, hipStream_t stream);
 hipError_t pq2_launch_select(const void *pieces, uint32_t n_pieces, hipStream_t stream);
+hipError_t pq2_launch_filtered(const void *pieces, uint32_t n_pieces, uint32_t *counts, hipStream_t stream);
 hipError_t pq2_launch_optional(const void *pages, uint32_t n_pages, uint32_t value_words, int32_t *status,
                                uint32_t seg_rows, uint32_t n_segs, uint32_t *seg_valid,
                                hipStream_t stream);
@@ -113,6 +114,11 @@ struct SelectPiece {  // must match pq2::SelectPiece
     uint32_t count, reserved;
 };
 static_assert(sizeof(SelectPiece) == 24, "SelectPiece layout");
+struct FilterPiece {  // must match pq2::FilterPiece
+    uint64_t src_addr, dst_addr;
+    uint32_t count, counter;
+};
+static_assert(sizeof(FilterPiece) == 24, "FilterPiece layout");
 constexpr uint64_t kSelectPieceValues = 16384;
 
 struct RawPageDev {  // must match pq2::RawPageDev
@@ -943,6 +949,80 @@ int32_t pq2_decode_selected_batch_device(pq2_ctx *ctx, const void *d_in, uint64_
         std::memcpy(ctx->h_gather, pieces.data(), bytes);
         if ((st = upload_block(ctx, bytes, stream))) return st;
         PQ2_HIP(ctx, pq2_launch_select(ctx->d_gather.ptr, static_cast<uint32_t>(pieces.size()), stream));
+    }
+    if (status) return fetch_status(ctx, status, n_pages);
+    return PQ2_OK;
+}
+
+int32_t pq2_filtered_validity_batch_device(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const pq2_page_desc *descs,
+                                           uint64_t n_pages, const pq2_interval *intervals,
+                                           const uint64_t *interval_offsets, uint8_t *d_validity, uint64_t validity_rows,
+                                           uint32_t *d_counts, int32_t *status, void *stream_) {
+    if (!ctx) return PQ2_INVALID_PARAMETER;
+    PQ2_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (n_pages > 0 && (!descs || !interval_offsets)) return fail(ctx, PQ2_INVALID_PARAMETER, "an array is NULL");
+    if ((reinterpret_cast<uintptr_t>(d_counts) & 3u) != 0) return fail(ctx, PQ2_INVALID_PARAMETER, "d_counts misaligned");
+    // every page's levels decoded in full into the context's buffer, 16-byte aligned
+    std::vector<pq2_page_desc> full(descs, descs + n_pages);
+    uint64_t at = 0;
+    for (uint64_t i = 0; i < n_pages; ++i) {
+        if (descs[i].num_bits != 1) return fail(ctx, PQ2_INVALID_PARAMETER, "levels of a bitmap are one bit wide");
+        full[i].out_off = at;
+        if (interval_offsets[i] > interval_offsets[i + 1])
+            return fail(ctx, PQ2_INVALID_PARAMETER, "interval_offsets must ascend");
+        if (interval_offsets[i] < interval_offsets[i + 1] && (!intervals || !d_counts))
+            return fail(ctx, PQ2_INVALID_PARAMETER, "intervals or d_counts is NULL");
+        uint64_t current = 0, selected = 0;
+        for (uint64_t k = interval_offsets[i]; k < interval_offsets[i + 1]; ++k) {
+            const pq2_interval &iv = intervals[k];
+            if (iv.length == 0 || iv.start < current || iv.start > descs[i].num_values ||
+                iv.length > descs[i].num_values - iv.start)
+                return fail(ctx, PQ2_INVALID_PARAMETER,
+                            "intervals must hold at least one row, ascend without overlap and end inside the page");
+            current = iv.start + iv.length;
+            selected += iv.length;
+        }
+        if (descs[i].out_off > validity_rows || selected > validity_rows - descs[i].out_off)
+            return fail(ctx, PQ2_INVALID_PARAMETER, "selected rows outside the validity buffer");
+        at += (descs[i].num_values + 3) & ~uint64_t(3);
+    }
+    const uint64_t n_intervals = n_pages ? interval_offsets[n_pages] : 0;
+    int32_t st;
+    if (ctx->busy && ctx->last_stream != stream) PQ2_HIP(ctx, hipStreamSynchronize(ctx->last_stream));
+    if ((st = reserve(ctx, ctx->d_indices, std::max<uint64_t>(at, 1) * sizeof(uint32_t)))) return st;
+    uint32_t *d_full = static_cast<uint32_t *>(ctx->d_indices.ptr);
+    if ((st = enqueue_batch(ctx, d_in, in_bytes, full.data(), n_pages, d_full, at, stream))) return st;
+    std::vector<FilterPiece> pieces;
+    for (uint64_t i = 0; i < n_pages; ++i) {
+        if (ctx->host_status[i] != PQ2_OK) continue;
+        uint64_t dst = descs[i].out_off, current = 0;
+        auto add = [&](uint64_t first, uint64_t rows, uint8_t *to, uint64_t counter) {
+            for (uint64_t o = 0; o < rows; o += kSelectPieceValues) {
+                FilterPiece pc;
+                pc.src_addr = reinterpret_cast<uint64_t>(d_full + full[i].out_off + first + o);
+                pc.dst_addr = to ? reinterpret_cast<uint64_t>(to + o) : 0;
+                pc.count = static_cast<uint32_t>(std::min<uint64_t>(kSelectPieceValues, rows - o));
+                pc.counter = static_cast<uint32_t>(counter);
+                pieces.push_back(pc);
+            }
+        };
+        for (uint64_t k = interval_offsets[i]; k < interval_offsets[i + 1]; ++k) {
+            add(current, intervals[k].start - current, nullptr, 2 * k);              // Skipped
+            add(intervals[k].start, intervals[k].length, d_validity + dst, 2 * k + 1);  // Bitmap / Repeated
+            current = intervals[k].start + intervals[k].length;
+            dst += intervals[k].length;
+        }
+    }
+    if (pieces.size() > 0x7fffffffull || n_intervals > 0x3fffffffull)
+        return fail(ctx, PQ2_INVALID_PARAMETER, "too many intervals in one batch");
+    if (n_intervals) PQ2_HIP(ctx, hipMemsetAsync(d_counts, 0, 2 * n_intervals * sizeof(uint32_t), stream));
+    if (!pieces.empty()) {
+        const size_t bytes = pieces.size() * sizeof(FilterPiece);
+        if ((st = stage_block(ctx, bytes, bytes))) return st;
+        std::memcpy(ctx->h_gather, pieces.data(), bytes);
+        if ((st = upload_block(ctx, bytes, stream))) return st;
+        PQ2_HIP(ctx, pq2_launch_filtered(ctx->d_gather.ptr, static_cast<uint32_t>(pieces.size()), d_counts, stream));
     }
     if (status) return fetch_status(ctx, status, n_pages);
     return PQ2_OK;

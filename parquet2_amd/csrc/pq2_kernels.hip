@@ -1345,6 +1345,54 @@ __global__ __launch_bounds__(256) void select_kernel(const SelectPiece *__restri
 }
 
 // ---------------------------------------------------------------------------
+// filtered_kernel: the definition levels of selected rows as validity bytes, and the counts of valid rows in and
+// between the selected intervals (FilteredHybridBitmapIter, src/deserialize/filtered_rle.rs:53-274: its Bitmap /
+// Repeated items are the bytes, its Skipped(set_count) items the counts).  One workgroup per piece of at most
+// 16384 rows of a decoded page: a piece of an interval writes its rows' bytes and adds its valid rows to the
+// interval's second counter, a piece of the rows in front of an interval only counts, into the first.
+// ---------------------------------------------------------------------------
+struct FilterPiece {  // must match the host's
+    uint64_t src_addr;  // the piece's first level (u32)
+    uint64_t dst_addr;  // where its validity bytes go; 0: rows that are skipped
+    uint32_t count;
+    uint32_t counter;   // which word of the counts its valid rows are added to
+};
+
+__global__ __launch_bounds__(256) void filtered_kernel(const FilterPiece *__restrict__ pieces, uint32_t *__restrict__ counts) {
+    __shared__ uint32_t wave_sum[4];
+    const FilterPiece pc = pieces[blockIdx.x];
+    typedef __attribute__((address_space(1))) const uint32_t gu32;
+    typedef __attribute__((address_space(1))) const u32x4 gu32x4;
+    typedef __attribute__((address_space(1))) uint8_t gu8;
+    gu32 *const src = (gu32 *)pc.src_addr;
+    gu8 *const dst = (gu8 *)pc.dst_addr;
+    uint32_t valid = 0, done = 0;
+    if ((pc.src_addr & 15u) == 0u && (pc.dst_addr & 3u) == 0u) {  // four rows a thread: one load, one store
+        const uint32_t quads = pc.count >> 2;
+        for (uint32_t q = threadIdx.x; q < quads; q += 256u) {
+            const u32x4 lv = ((gu32x4 *)src)[q];
+            const uint32_t b = (lv.x == 1u ? 1u : 0u) | (lv.y == 1u ? 0x100u : 0u) | (lv.z == 1u ? 0x10000u : 0u) |
+                               (lv.w == 1u ? 0x1000000u : 0u);
+            valid += (uint32_t)__popc(b);
+            if (dst) *(__attribute__((address_space(1))) uint32_t *)(dst + 4u * q) = b;
+        }
+        done = quads << 2;
+    }
+    for (uint32_t i = done + threadIdx.x; i < pc.count; i += 256u) {
+        const uint32_t v = src[i] == 1u ? 1u : 0u;
+        valid += v;
+        if (dst) dst[i] = (uint8_t)v;
+    }
+    valid = wave_inclusive_sum(valid);
+    if ((threadIdx.x & 63u) == 63u) wave_sum[threadIdx.x >> 6] = valid;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t all = wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
+        if (all) atomicAdd(&counts[pc.counter], all);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // front_kernel: split_buffer_v1 (src/page/mod.rs:350-398) and the width byte of
 // dictionary indices (src/deserialize/utils.rs:13-27) for page buffers that lie
 // in device memory.  The host has built three stream descriptors per page
@@ -2069,6 +2117,12 @@ extern "C" hipError_t pq2_launch_optional(const void *pages, uint32_t n_pages, u
 extern "C" hipError_t pq2_launch_select(const void *pieces, uint32_t n_pieces, hipStream_t stream) {
     if (n_pieces == 0) return hipSuccess;
     hipLaunchKernelGGL(pq2::select_kernel, dim3(n_pieces), dim3(256), 0, stream, (const pq2::SelectPiece *)pieces);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t pq2_launch_filtered(const void *pieces, uint32_t n_pieces, uint32_t *counts, hipStream_t stream) {
+    if (n_pieces == 0) return hipSuccess;
+    hipLaunchKernelGGL(pq2::filtered_kernel, dim3(n_pieces), dim3(256), 0, stream, (const pq2::FilterPiece *)pieces, counts);
     return hipGetLastError();
 }
 

@@ -1194,7 +1194,8 @@ template <bool kWide, int kWords>
 __global__ __launch_bounds__(kRingThreads, PQ2_RING_MIN_WAVES) void ring_kernel(const PageDev *__restrict__ pages, uint32_t n_pages,
                                                        int32_t *__restrict__ status, uint32_t *__restrict__ cu_tickets,
                                                        uint32_t ring_bytes, const uint32_t *__restrict__ tile_mask,
-                                                       const RingDict *__restrict__ dicts, uint32_t dict_at) {
+                                                       const RingDict *__restrict__ dicts, uint32_t dict_at,
+                                                       uint32_t whole_tile_spans) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1268,7 +1269,10 @@ __global__ __launch_bounds__(kRingThreads, PQ2_RING_MIN_WAVES) void ring_kernel(
             const uint32_t tile_first = t * kRingTileValues;
             out_u32 *const out = (out_u32 *)pg.out_addr + tile_first;
             // pages of levels: the tile as one span
-            const uint32_t span_blocks = (kWords == 0 && kRingTileBlocks == 4 && w != 0u && w <= kRingWholeTileBits) ? 4u : kRingSpanBlocks;
+            // (`whole_tile_spans`: the launcher says so for batches of nothing but such pages; beside wider pages the
+            // whole-tile spans cost more than they bring: configs[4]'s mix loses 2.6 % with them)
+            const uint32_t span_blocks =
+                (kWords == 0 && kRingTileBlocks == 4 && whole_tile_spans != 0u && w != 0u && w <= kRingWholeTileBits) ? 4u : kRingSpanBlocks;
             const uint32_t span_values = span_blocks * kBlockValues;
             for (uint32_t i = 0; i < kRingTileBlocks / span_blocks; ++i) {
                 const uint32_t span_first = tile_first + i * span_values;
@@ -1291,7 +1295,10 @@ __global__ __launch_bounds__(kRingThreads, PQ2_RING_MIN_WAVES) void ring_kernel(
         break;
 #define PQ2_W_LEVELS(N)                                                                                                     \
     case N:                                                                                                                 \
-        ring_expand_span<N, kRingTileBlocks == 4 ? 4 : 2>(io, tbl, cidx, rs, end, n, span_first, span_n, sink, lane);       \
+        if (span_blocks == 4u)                                                                                              \
+            ring_expand_span<N, kRingTileBlocks == 4 ? 4 : 2>(io, tbl, cidx, rs, end, n, span_first, span_n, sink, lane);   \
+        else                                                                                                                \
+            ring_expand_span<N, kRingSpanBlocks>(io, tbl, cidx, rs, end, n, span_first, span_n, sink, lane);                \
         break;
                 if constexpr (kWords == 0) {
                     IndexSink sink = {out + i * span_values};

@@ -23,6 +23,8 @@ extern "C" hipError_t pq2_launch_ring(const void *pages, uint32_t n_pages, int32
         if (b == 16384u || b == 32768u || b == 65536u) ring_bytes = b;
     }
     const uint32_t lds_bytes = pq2::ring_lds_bytes(ring_bytes);
+    // a batch of nothing but levels: whole tiles as spans (see kRingWholeTileBits)
+    const uint32_t whole_tile_spans = max_bits != 0u && max_bits <= pq2::kRingWholeTileBits ? 1u : 0u;
     if (max_bits > 16u) {
         // more than 64 KiB of dynamic LDS has to be asked for (per device; the call is cheap)
         if (lds_bytes > 65536u) {
@@ -32,11 +34,11 @@ extern "C" hipError_t pq2_launch_ring(const void *pages, uint32_t n_pages, int32
         }
         hipLaunchKernelGGL((pq2::ring_kernel<true, 0>), dim3(n_pages), dim3(pq2::kRingThreads), lds_bytes, stream,
                            (const pq2::PageDev *)pages, n_pages, status, cu_tickets, ring_bytes, tile_mask,
-                           (const pq2::RingDict *)nullptr, 0u);
+                           (const pq2::RingDict *)nullptr, 0u, whole_tile_spans);
     } else {
         hipLaunchKernelGGL((pq2::ring_kernel<false, 0>), dim3(n_pages), dim3(pq2::kRingThreads), lds_bytes, stream,
                            (const pq2::PageDev *)pages, n_pages, status, cu_tickets, ring_bytes, tile_mask,
-                           (const pq2::RingDict *)nullptr, 0u);
+                           (const pq2::RingDict *)nullptr, 0u, whole_tile_spans);
     }
     return hipGetLastError();
 }

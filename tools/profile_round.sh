@@ -35,6 +35,8 @@ for fused in 1 0; do
   done
 done
 timeout -k 10 200 python3 $R/tools/scout_rounds.py > $O/scout_rounds.txt 2>&1 || exit 1
+timeout -k 10 200 python3 $R/tools/bench_bitunpack64.py > $O/bitunpack64.json 2> $O/bitunpack64.err || exit 1
+(timeout -k 10 200 python3 $R/tools/bench_optional.py 4096 262144 4 && timeout -k 10 200 python3 $R/tools/bench_optional.py 16 4194304 4 && PQ2_OPTIONAL_SEG_ROWS=0 timeout -k 10 200 python3 $R/tools/bench_optional.py 16 4194304 4) > $O/optional.txt 2> $O/optional.err || exit 1
 cd $R
 python3 tools/traffic.py $O/pmc_fetch $O/pmc_write 4 $O/traffic.json '{"workload": "dict", "pages_per_gpu": 2048, "values_per_page": 1048576, "num_bits": 12}' > /dev/null
 cp $(find $O/pmc_fetch -name '*counter_collection.csv' | head -1) $O/pmc_fetch_size.csv

@@ -12,13 +12,17 @@
 //            end of the tile.  Everything unusual (a varint of three or more bytes, a run that passes the end of
 //            the stream or reaches further than 32 KiB from the tile) is an escape that names the header, which
 //            is then decoded exactly by whoever gets there.  2 bytes per stream byte, written once.
-//   resolve  one workgroup per page: every tile starts with a guess of where it is entered (its first byte), and
-//            each round looks up, for all tiles at once, where the chain from that entry leaves the tile, marks the
-//            tiles that the chain from the page's first byte reaches (pointer doubling over the tiles) and hands
-//            each reached tile's exit to the tile it lands in.  The page's first tile is right from the start, so
-//            every round makes at least one more tile right; as chains that start at different offsets fall into
-//            step after a few headers, two or three rounds do for real data.  The result is exact either way: it
-//            is the fixed point in which every reached tile is entered where its predecessor leaves.
+//            It also counts, per tile, at which offsets of the next tile most of its chains arrive (votes): the
+//            four strongest are handed on as guesses of where the page's chain enters that tile.
+//   resolve  one workgroup per page.  First the votes are carried forward from tile to tile through the tables
+//            (the page's chain goes on and on, a chain that starts inside a payload soon ends: after a few tiles the
+//            true entry has the most votes even where headers are hundreds of bytes apart).  Then every tile starts
+//            with its strongest candidate, and each round looks up, for all tiles at once, where the chain from
+//            that entry leaves the tile, marks the tiles that the chain from the page's first byte reaches (pointer
+//            doubling over the tiles) and hands each reached tile's exit to the tile it lands in.  The page's first
+//            tile is right from the start, so every round makes at least one more tile right; with good guesses
+//            one to three rounds do.  The result is exact either way: it is the fixed point in which every
+//            reached tile is entered where its predecessor leaves.
 //   count    one wave per reached tile walks the tile's part of the chain (the chase loop of parse_kernel, out of
 //            LDS), sums the values its runs hold and lists the runs that hold any (2 bytes per run, over the
 //            tile's table, which nobody needs any more).
@@ -58,6 +62,15 @@ constexpr uint32_t kScoutVoters = PQ2_SCOUT_VOTERS;         // the offsets of th
 #define PQ2_SCOUT_DENSE 40
 #endif
 constexpr uint32_t kScoutDense = PQ2_SCOUT_DENSE;           // headers per tile from which the count step works lane-parallel
+constexpr uint32_t kScoutKeep = 4;                          // exits of a tile the table step hands on, most voted first
+constexpr uint32_t kScoutResolveThreads = 1024;             // threads of the resolve step's one workgroup per page
+constexpr uint32_t kScoutResolveArrays = 12;                // arrays of kScoutLdsTiles + 8 words it keeps in LDS
+constexpr uint32_t kScoutSure = 96;                         // votes (of 2048) from which the first exit is handed on alone
+#ifndef PQ2_SCOUT_PUSHES
+#define PQ2_SCOUT_PUSHES 12
+#endif
+constexpr uint32_t kScoutPushes = PQ2_SCOUT_PUSHES;         // tiles a vote is carried forward at most (resolve step)
+static_assert(kScoutBins * 2u == kScoutTile, "two exits share a vote counter: one in either half of the next tile");
 
 struct ScoutPage {
     uint32_t tile_base;  // batch-wide number of the page's first stream tile
@@ -160,7 +173,8 @@ __device__ __forceinline__ void scout_segments(const SegBytes &sb, const uint32_
 __global__ __launch_bounds__(256) void scout_table_kernel(const PageDev *__restrict__ pages,
                                                           const ScoutPage *__restrict__ sp, uint32_t *__restrict__ tiles,
                                                           uint16_t *__restrict__ table, uint32_t n_stiles,
-                                                          const ParseState *__restrict__ state) {
+                                                          const ParseState *__restrict__ state,
+                                                          uint32_t *__restrict__ hints) {
     __shared__ __attribute__((aligned(16))) uint16_t lds[4][kScoutTable];
     __shared__ uint32_t votes[4][kScoutBins / 2u];  // two 16-bit counters per word
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -205,9 +219,11 @@ __global__ __launch_bounds__(256) void scout_table_kernel(const PageDev *__restr
         }
         wave_sync();
     }
-    // A guess at where the page's chain enters the next tile: the offset there at which most of this tile's chains
+    // Guesses at where the page's chain enters the next tile: the offsets there at which most of this tile's chains
     // arrive.  Every header of the page's chain inside this tile is an offset that votes for the true one, while
-    // the chains that start inside bit-packed payloads scatter.  (Only a guess: the resolve step decides.)
+    // the chains that start inside bit-packed payloads scatter -- but they gather too (a few dozen offsets of random
+    // bytes may lead to one place), so where headers are sparse the true exit is often not the first but among the
+    // first few: kScoutKeep of them are handed on with their votes.  (Only guesses: the resolve step decides.)
     {
         uint32_t *const vote = votes[wave];
 #pragma unroll
@@ -216,8 +232,10 @@ __global__ __launch_bounds__(256) void scout_table_kernel(const PageDev *__restr
         // (the offsets of a segment that leave the tile at the same place -- in a stretch of short runs, all of them --
         // vote together)
         auto cast = [&](uint32_t v, uint32_t times) {
-            if (v >= kScoutTile && v < 2u * kScoutTile && lane < kScoutVoters)
-                atomicAdd(&vote[((v - kScoutTile) & (kScoutBins - 1u)) >> 1], times << ((v & 1u) * 16u));
+            if (v >= kScoutTile && v < 2u * kScoutTile && lane < kScoutVoters) {
+                const uint32_t rel = v - kScoutTile, bin = rel & (kScoutBins - 1u);
+                atomicAdd(&vote[bin >> 1], times << ((bin & 1u) * 16u));
+            }
         };
         uint32_t same = tbl[lane], times = 1u;
 #pragma unroll 4
@@ -231,31 +249,95 @@ __global__ __launch_bounds__(256) void scout_table_kernel(const PageDev *__restr
         }
         cast(same, times);
         wave_sync();
-        uint32_t best = 0;  // votes << 10 | counter
+        // the counter with the most votes (votes << 10 | counter)
+        constexpr uint32_t kMine = kScoutBins / 64u;  // counters per lane
+        uint32_t top[kScoutKeep];
+        {
+            uint32_t best = 0;
 #pragma unroll
-        for (uint32_t i = 0; i < kScoutBins / 2u / 64u; ++i) {
-            const uint32_t at = lane * (kScoutBins / 2u / 64u) + i;
-            const uint32_t word = vote[at];
-            best = max(best, ((word & 0xffffu) << 10) | (2u * at));
-            best = max(best, ((word >> 16) << 10) | (2u * at + 1u));
+            for (uint32_t i = 0; i < kMine / 2u; ++i) {
+                const uint32_t at = lane * (kMine / 2u) + i;
+                const uint32_t word = vote[at];
+                best = max(best, ((word & 0xffffu) << 10) | (2u * at));
+                best = max(best, ((word >> 16) << 10) | (2u * at + 1u));
+            }
+            top[0] = __builtin_amdgcn_readlane(wave_inclusive_max(best), 63);
         }
-        best = __builtin_amdgcn_readlane(wave_inclusive_max(best), 63);
-        // the two exits that share the winning counter: the one more of the voters leave at
-        const uint32_t near = kScoutTile + (best & (kScoutBins - 1u)), far = near + kScoutBins;
-        uint32_t n_near = 0, n_far = 0;
-        if (lane < kScoutVoters) {
-#pragma unroll 4
-            for (uint32_t i = 0; i < kScoutSeg; ++i) {
-                const uint32_t v = tbl[i * kScoutRow + lane];
-                n_near += v == near ? 1u : 0u;
-                n_far += v == far ? 1u : 0u;
+#pragma unroll
+        for (uint32_t r = 1; r < kScoutKeep; ++r) top[r] = 0u;
+        // ... and the next ones, unless nearly all chains of the tile leave it together (dense headers: no need for a
+        // second guess)
+        if ((top[0] >> 10) < kScoutSure) {
+            uint32_t mine[kMine];
+#pragma unroll
+            for (uint32_t i = 0; i < kMine / 2u; ++i) {
+                const uint32_t at = lane * (kMine / 2u) + i;
+                const uint32_t word = vote[at];
+                mine[2u * i] = ((word & 0xffffu) << 10) | (2u * at);
+                mine[2u * i + 1u] = ((word >> 16) << 10) | (2u * at + 1u);
+            }
+#pragma unroll
+            for (uint32_t r = 1; r < kScoutKeep; ++r) {
+                uint32_t best = 0;
+#pragma unroll
+                for (uint32_t i = 0; i < kMine; ++i) {
+                    mine[i] = mine[i] == top[r - 1u] ? 0u : mine[i];
+                    best = max(best, mine[i]);
+                }
+                top[r] = __builtin_amdgcn_readlane(wave_inclusive_max(best), 63);
             }
         }
-        n_near = __builtin_amdgcn_readlane(wave_inclusive_sum(n_near), 63);
-        n_far = __builtin_amdgcn_readlane(wave_inclusive_sum(n_far), 63);
+        // the two exits that share a counter (one in the near half of the next tile, one in the far half): how many
+        // of the voters leave at either (near | far << 16)
+        const bool sure = (top[0] >> 10) >= kScoutSure;
+        uint32_t both[kScoutKeep];
+#pragma unroll
+        for (uint32_t r = 0; r < kScoutKeep; ++r) both[r] = 0u;
+        if (lane < kScoutVoters) {
+            if (sure) {
+#pragma unroll 4
+                for (uint32_t i = 0; i < kScoutSeg; ++i) {
+                    const uint32_t rel = (uint32_t)tbl[i * kScoutRow + lane] - kScoutTile;
+                    const uint32_t one = rel < kScoutBins ? 1u : rel < kScoutTile ? 0x10000u : 0u;
+                    both[0] += (rel & (kScoutBins - 1u)) == (top[0] & (kScoutBins - 1u)) ? one : 0u;
+                }
+            } else {
+#pragma unroll 4
+                for (uint32_t i = 0; i < kScoutSeg; ++i) {
+                    const uint32_t rel = (uint32_t)tbl[i * kScoutRow + lane] - kScoutTile;
+                    const uint32_t one = rel < kScoutBins ? 1u : rel < kScoutTile ? 0x10000u : 0u;
+#pragma unroll
+                    for (uint32_t r = 0; r < kScoutKeep; ++r)
+                        both[r] += (rel & (kScoutBins - 1u)) == (top[r] & (kScoutBins - 1u)) ? one : 0u;
+                }
+            }
+        }
+#pragma unroll
+        for (uint32_t r = 0; r < kScoutKeep; ++r)
+            both[r] = (sure && r != 0u) || (top[r] >> 10) == 0u ? 0u : __builtin_amdgcn_readlane(wave_inclusive_sum(both[r]), 63);
+        const uint32_t n_near = both[0] & 0xffffu, n_far = both[0] >> 16;
         if (lane == 0) {
+            const uint32_t near = kScoutTile + (top[0] & (kScoutBins - 1u)), far = near + kScoutBins;
             t.exit[g] = max(n_near, n_far) >= 2u ? t0 + (n_far > n_near ? far : near) : kScoutNone;
             t.vals[g] = max(n_near, n_far);  // about as many headers as the page's chain has in this tile (count step)
+        }
+        // Candidates for the entry of the next tile: (offset in that tile) << 16 | votes, two votes at least, the
+        // first kScoutKeep of: the winning counter's two exits (the one with more voters first), then the other
+        // counters' (near, far).  Lanes 2 r and 2 r + 1 hold counter r's.
+        {
+            const uint32_t r = lane >> 1, is_far = lane & 1u;
+            const uint32_t top_r = r == 0u ? top[0] : r == 1u ? top[1] : r == 2u ? top[2] : top[3];
+            const uint32_t both_r = r == 0u ? both[0] : r == 1u ? both[1] : r == 2u ? both[2] : both[3];
+            static_assert(kScoutKeep == 4u, "lanes 0..7 hold the candidates");
+            const bool want_far = (is_far != 0u) != (r == 0u && n_far > n_near);
+            const uint32_t rel = (top_r & (kScoutBins - 1u)) + (want_far ? kScoutBins : 0u);
+            const uint32_t count = want_far ? both_r >> 16 : both_r & 0xffffu;
+            const bool valid = lane < 2u * kScoutKeep && count >= 2u;
+            const uint64_t valids = __ballot(valid);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_lo((uint32_t)valids, 0u);  // lanes below 32 only
+            uint32_t *const out = hints + (size_t)g * kScoutKeep;
+            if (valid && rank < kScoutKeep) out[rank] = (rel << 16) | count;
+            if (lane < kScoutKeep && lane >= (uint32_t)__popcll(valids)) out[lane] = 0u;
         }
     }
     // the table as it lies in LDS: kScoutTable * 2 = 4224 bytes = 264 pieces of 16
@@ -290,15 +372,17 @@ __device__ __forceinline__ uint32_t scout_leave(const PageDev &pg, const __amdgp
     }
 }
 
-// One workgroup per page.  Dynamic LDS: six arrays of kScoutLdsTiles + 8 words; pages with more tiles use
-// `scratch` (six arrays of n_tiles + 8 words from word 6 * (tile_base + 8 * page) on).
-__global__ __launch_bounds__(256) void scout_resolve_kernel(const PageDev *__restrict__ pages,
+// One workgroup per page.  Dynamic LDS: kScoutResolveArrays arrays of kScoutLdsTiles + 8 words (six for the rounds,
+// twelve while votes are carried forward); pages with more tiles use `scratch` (six arrays of n_tiles + 8 words from
+// word 6 * (tile_base + 8 * page) on) and do without the carried votes.
+__global__ __launch_bounds__(kScoutResolveThreads) void scout_resolve_kernel(const PageDev *__restrict__ pages,
                                                             const ScoutPage *__restrict__ sp, uint32_t n_pages,
                                                             const uint16_t *__restrict__ table,
                                                             uint32_t *__restrict__ tiles, uint32_t n_stiles,
                                                             uint32_t *__restrict__ scratch,
                                                             uint32_t *__restrict__ rounds_out,
-                                                            const ParseState *__restrict__ state) {
+                                                            const ParseState *__restrict__ state,
+                                                            const uint32_t *__restrict__ hints) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_words[];
     __shared__ uint32_t changed;
     const uint32_t page = blockIdx.x;
@@ -327,14 +411,98 @@ __global__ __launch_bounds__(256) void scout_resolve_kernel(const PageDev *__res
     const uint32_t tid = threadIdx.x;
     auto tile_of = [&](uint32_t x) { return x >= kScoutGaveUp ? n : min(x / kScoutTile, n); };
 
-    // first guesses: the page's first byte; elsewhere what the table step saw most chains of the tile before arrive
-    // at, or the tile's first byte
-    for (uint32_t k = tid; k < n; k += 256u) {
+    // Votes carried forward.  The page's chain goes on from tile to tile while a chain that starts in a payload soon
+    // ends in a header nobody follows, so of the exits that the chains of tile k - 1 vote for, the true one is the
+    // one whose voters come from far back.  best[i][k]: candidates for the entry of tile k, (offset in the tile)
+    // << 16 | votes; every pass adds to the votes of tile k - 1's own chains those of best[.][k - 1], carried through
+    // tile k - 1 by its table, and keeps the kScoutKeep strongest: after d passes the votes of d + 1 tiles count.
+    // It ends when no tile's strongest candidate changes.  (In LDS, over arrays that are not in use yet.)
+    const bool carry_votes = kScoutPushes != 0u && n <= kScoutLdsTiles;
+    if (carry_votes) {
+        uint32_t *const best = arrays;                  // best[i * stride + k]
+        uint32_t *const carried = arrays + 4 * stride;  // ... what arrives in tile k from the candidates of tile k - 1
+        uint32_t *const own = arrays + 8 * stride;      // ... what the table step handed on
+        static_assert(kScoutKeep == 4u, "candidates are loaded four at a time, and the arrays are laid out for four");
+        for (uint32_t k = tid; k < n; k += kScoutResolveThreads) {
+            u32x4 h = {(delta << 16) | 0xffffu, 0u, 0u, 0u};  // the page's first byte: known
+            if (k != 0u) h = *(const u32x4 *)(hints + ((size_t)s.tile_base + k - 1u) * kScoutKeep);
+            own[k] = h.x, own[stride + k] = h.y, own[2 * stride + k] = h.z, own[3 * stride + k] = h.w;
+            best[k] = h.x, best[stride + k] = h.y, best[2 * stride + k] = h.z, best[3 * stride + k] = h.w;
+        }
+        for (uint32_t pass = 0; pass < kScoutPushes; ++pass) {
+            __syncthreads();
+            if (tid == 0) changed = 0u;
+#pragma unroll 2
+            for (uint32_t k = tid + 1u; k < n; k += kScoutResolveThreads) {
+                uint32_t c[kScoutKeep], v[kScoutKeep];
+#pragma unroll
+                for (uint32_t i = 0; i < kScoutKeep; ++i) {
+                    c[i] = best[i * stride + k - 1u];
+                    v[i] = page_table[(size_t)(k - 1u) * kScoutTable + table_slot((c[i] >> 16) & (kScoutTile - 1u))];
+                }
+#pragma unroll
+                for (uint32_t i = 0; i < kScoutKeep; ++i) {
+                    const bool lands = (c[i] & 0xffffu) != 0u && v[i] >= kScoutTile && v[i] < 2u * kScoutTile;
+                    carried[i * stride + k] = lands ? ((v[i] - kScoutTile) << 16) | (c[i] & 0xffffu) : 0u;
+                }
+            }
+            __syncthreads();
+#pragma unroll 1
+            for (uint32_t k = tid + 1u; k < n; k += kScoutResolveThreads) {
+                uint32_t rel[2u * kScoutKeep], cnt[2u * kScoutKeep];
+#pragma unroll
+                for (uint32_t i = 0; i < kScoutKeep; ++i) {
+                    const uint32_t o = own[i * stride + k], a = carried[i * stride + k];
+                    rel[i] = o >> 16, cnt[i] = o & 0xffffu;
+                    rel[kScoutKeep + i] = a >> 16, cnt[kScoutKeep + i] = a & 0xffffu;
+                }
+                // votes for one offset count together (the table step's candidates are different offsets already)
+#pragma unroll
+                for (uint32_t i = kScoutKeep; i < 2u * kScoutKeep; ++i) {
+#pragma unroll
+                    for (uint32_t j = 0; j < i; ++j) {
+                        if (cnt[i] != 0u && cnt[j] != 0u && rel[i] == rel[j]) {
+                            cnt[j] = min(cnt[j] + cnt[i], 0xffffu);
+                            cnt[i] = 0u;
+                        }
+                    }
+                }
+                uint32_t key[2u * kScoutKeep];  // votes << 16 | offset
+#pragma unroll
+                for (uint32_t i = 0; i < 2u * kScoutKeep; ++i) key[i] = cnt[i] != 0u ? (cnt[i] << 16) | rel[i] : 0u;
+                const uint32_t was = best[k];
+#pragma unroll
+                for (uint32_t r = 0; r < kScoutKeep; ++r) {
+                    uint32_t most = 0;
+#pragma unroll
+                    for (uint32_t i = 0; i < 2u * kScoutKeep; ++i) most = max(most, key[i]);
+#pragma unroll
+                    for (uint32_t i = 0; i < 2u * kScoutKeep; ++i) key[i] = key[i] == most ? 0u : key[i];
+                    best[r * stride + k] = (most << 16) | (most >> 16);
+                    if (r == 0u && (was >> 16) != (most & 0xffffu)) changed = 1u;
+                }
+            }
+            __syncthreads();
+            if (changed == 0u) break;
+        }
+        // (the strongest candidates move to where the rounds below do not write before they are read)
+        for (uint32_t k = tid; k < n; k += kScoutResolveThreads) own[k] = best[k];
+        __syncthreads();
+    }
+
+    // first guesses: the page's first byte; elsewhere the candidate with the most votes (for a page too large for
+    // the passes above: what the table step saw most chains of the tile before arrive at), or the tile's first byte
+    for (uint32_t k = tid; k < n; k += kScoutResolveThreads) {
         uint32_t x = k == 0u ? delta : k * kScoutTile;
         bool guess = k != 0u;
         if (k != 0u) {
-            const uint32_t hint = t.exit[s.tile_base + k - 1u];
-            if (hint != kScoutNone && hint / kScoutTile == k) x = hint, guess = false;
+            if (carry_votes) {
+                const uint32_t h = arrays[8 * stride + k];
+                if ((h & 0xffffu) >= 2u) x = k * kScoutTile + (h >> 16), guess = false;
+            } else {
+                const uint32_t hint = t.exit[s.tile_base + k - 1u];
+                if (hint != kScoutNone && hint / kScoutTile == k) x = hint, guess = false;
+            }
         }
         cand[k] = x;
         // (the first byte of a tile is rarely a header: such a guess is not followed, the tile waits for an offer)
@@ -351,7 +519,7 @@ __global__ __launch_bounds__(256) void scout_resolve_kernel(const PageDev *__res
         ++iter_count;
         __syncthreads();
         if (tid == 0) changed = 0u;
-        for (uint32_t k = tid; k < n; k += 256u) {
+        for (uint32_t k = tid; k < n; k += kScoutResolveThreads) {
             const uint32_t f = flag[k];
             if (f & 1u)
                 leave[k] = scout_leave(pg, rsrc, end, page_table, cand[k], (k == 0u || (f & 4u)) ? 0xffffffffu : kScoutGuessEscapes);
@@ -365,7 +533,7 @@ __global__ __launch_bounds__(256) void scout_resolve_kernel(const PageDev *__res
         for (uint32_t r = 0; r <= rounds; ++r) {
             const uint32_t *const from = jump[r & 1u];
             uint32_t *const to = jump[(r & 1u) ^ 1u];
-            for (uint32_t k = tid; k <= n; k += 256u) {
+            for (uint32_t k = tid; k <= n; k += kScoutResolveThreads) {
                 const uint32_t j = from[k];
                 if (flag[k] & 2u) flag[j] |= 2u;  // (tile n stands for "nowhere")
                 to[k] = from[j];
@@ -375,7 +543,7 @@ __global__ __launch_bounds__(256) void scout_resolve_kernel(const PageDev *__res
         // Every tile hands its exit to the tile it lands in.  A reached tile's offer counts before any other (the
         // reached tiles are one chain, so at most one of them lands in a tile); among the others, which only
         // speed things up where their own guess is right, the nearest one.
-        for (uint32_t k = tid; k < n; k += 256u) {
+        for (uint32_t k = tid; k < n; k += kScoutResolveThreads) {
             const uint32_t m = tile_of(leave[k]);
             if (m < n) atomicMax(&offer[m], ((flag[k] & 2u) << 30) | (k + 1u));
             if ((flag[k] & 2u) && leave[k] == kScoutGaveUp) {  // reached after all: the whole chain next time
@@ -384,7 +552,7 @@ __global__ __launch_bounds__(256) void scout_resolve_kernel(const PageDev *__res
             }
         }
         __syncthreads();
-        for (uint32_t m = tid; m < n; m += 256u) {
+        for (uint32_t m = tid; m < n; m += kScoutResolveThreads) {
             const uint32_t o = offer[m];
             if (o == 0u) continue;
             const uint32_t x = leave[(o & 0x7fffffffu) - 1u];
@@ -398,7 +566,7 @@ __global__ __launch_bounds__(256) void scout_resolve_kernel(const PageDev *__res
         if (changed == 0u) break;  // every reached tile is entered where its predecessor leaves
     }
     if (tid == 0) rounds_out[page] = iter_count;
-    for (uint32_t k = tid; k < n; k += 256u) {
+    for (uint32_t k = tid; k < n; k += kScoutResolveThreads) {
         const bool reached = (flag[k] & 2u) != 0u;
         t.entry[s.tile_base + k] = reached ? cand[k] : kScoutNone;
         t.exit[s.tile_base + k] = leave[k];
@@ -759,7 +927,8 @@ extern "C" size_t pq2_scout_table_bytes(uint64_t n_stiles) { return (size_t)n_st
 // where, in `words`, the resolve step leaves the number of rounds it took for every page (diagnostics)
 extern "C" size_t pq2_scout_rounds_at(uint64_t n_stiles, uint64_t n_pages) { return (7u * (size_t)n_stiles + 2u * (size_t)n_pages) * 4u; }
 extern "C" size_t pq2_scout_words_bytes(uint64_t n_stiles, uint64_t n_pages) {
-    return (7u * (size_t)n_stiles + 3u * (size_t)n_pages + 6u * ((size_t)n_stiles + 8u * (size_t)n_pages) + 16u) * 4u;
+    return (7u * (size_t)n_stiles + 3u * (size_t)n_pages + 6u * ((size_t)n_stiles + 8u * (size_t)n_pages) +
+            pq2::kScoutKeep * (size_t)n_stiles + 20u) * 4u;
 }
 
 // The header walk of a whole batch.  `spages`: n_pages ScoutPage records (device); `table`, `words`: scratch of
@@ -786,13 +955,19 @@ extern "C" hipError_t pq2_launch_scout(const void *pages, const void *spages, ui
     ScoutFin *fin = (ScoutFin *)(tiles + 7u * (size_t)n_stiles);
     uint32_t *rounds = (uint32_t *)(fin + n_pages);  // per page: rounds of the resolve step (pq2_scout_rounds_at)
     uint32_t *scratch = rounds + n_pages;
+    // kScoutKeep words per stream tile, at a multiple of 16 bytes
+    uint32_t *hints = tiles + ((13u * (size_t)n_stiles + 51u * (size_t)n_pages + 3u) & ~(size_t)3u);
     uint16_t *tbl = (uint16_t *)table;
     const uint32_t tile_groups = (n_stiles + 3u) / 4u;
     if (n_stiles != 0u) {
         hipLaunchKernelGGL(scout_map_kernel, dim3(n_pages), dim3(256), 0, stream, sp, n_pages, tiles, n_stiles);
-        hipLaunchKernelGGL(scout_table_kernel, dim3(tile_groups), dim3(256), 0, stream, pg, sp, tiles, tbl, n_stiles, done);
-        hipLaunchKernelGGL(scout_resolve_kernel, dim3(n_pages), dim3(256), 6u * (kScoutLdsTiles + 8u) * 4u, stream, pg, sp,
-                           n_pages, tbl, tiles, n_stiles, scratch, rounds, done);
+        hipLaunchKernelGGL(scout_table_kernel, dim3(tile_groups), dim3(256), 0, stream, pg, sp, tiles, tbl, n_stiles, done,
+                           hints);
+        constexpr uint32_t kResolveLds = kScoutResolveArrays * (kScoutLdsTiles + 8u) * 4u;  // above the 64 KiB a kernel gets unasked
+        e = hipFuncSetAttribute((const void *)scout_resolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kResolveLds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(scout_resolve_kernel, dim3(n_pages), dim3(kScoutResolveThreads), kResolveLds, stream, pg, sp,
+                           n_pages, tbl, tiles, n_stiles, scratch, rounds, done, hints);
         if (max_bits > 16u)
             hipLaunchKernelGGL(scout_count_kernel<true>, dim3(tile_groups), dim3(256), 0, stream, pg, sp, tiles, tbl, n_stiles, done);
         else

@@ -238,3 +238,18 @@ def test_pages_without_a_walk_among_others(scout, oracle):
             stream, _ = synth.dict_page(k, n, w, 10.0, 20.0)
             pages.append((stream, w, n + (k % 3) * 100))
     check_batch(scout, oracle, pages, align=1)
+
+
+def test_sparse_headers_at_several_widths(scout, oracle):
+    """Pages whose headers lie hundreds of bytes apart (long bit-packed runs of random values between short RLE
+    runs): the chains that start inside the payloads outnumber the page's own, so the first guess at a tile's entry
+    comes from votes carried over several tiles.  Exact whatever the guesses were; at width 12 the guesses are
+    good enough for the resolve step to be done in a few rounds."""
+    pages = []
+    for k, w in enumerate((12, 12, 12, 12, 20, 20, 27, 32)):
+        n = 1 << 18
+        stream, _ = synth.dict_page(synth.seed_for(2, 100 + k), n, w)
+        pages.append((stream, w, n))
+    check_batch(scout, oracle, pages)
+    rounds = scout.scout_rounds(len(pages))
+    assert rounds.min() >= 1 and rounds[:4].max() <= 4, rounds

@@ -1,0 +1,108 @@
+// What the memory system gives for the access pattern of the page-per-workgroup kernels, without any decoding:
+// every workgroup reads 6 KiB and writes 16 KiB per step (the 3 : 8 of bit width 12 expanded to u32), either
+//   pattern 0: steps dealt round robin over the whole grid (all workgroups write inside one moving window), or
+//   pattern 1: every workgroup walks through regions of its own (4 MiB written, 1.5 MiB read: a page of 2^20 values),
+//              as a kernel that holds one page per workgroup has to;
+//   pattern 2: as 1, each workgroup beginning at another offset of its region (regions that are a power of two
+//              apart, walked in step, meet in the same memory channels).
+// Build: hipcc -O3 --offload-arch=gfx950 tools/stream_pattern.hip -o gpurun_out/stream_pattern
+// Run:   gpurun_out/stream_pattern [regions = 2048] [workgroups = 1024] [threads = 256 | 128]
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+
+#define CHECK(x)                                                                                   \
+    do {                                                                                           \
+        hipError_t e_ = (x);                                                                       \
+        if (e_ != hipSuccess) {                                                                    \
+            fprintf(stderr, "%s:%d: %s\n", __FILE__, __LINE__, hipGetErrorString(e_));             \
+            exit(1);                                                                               \
+        }                                                                                          \
+    } while (0)
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr uint32_t kOutStep = 16384, kInStep = 6144;        // bytes per workgroup step
+constexpr uint32_t kRegionSteps = 256;                      // steps per region: 4 MiB written
+constexpr uint64_t kRegionOut = (uint64_t)kOutStep * kRegionSteps, kRegionIn = (uint64_t)kInStep * kRegionSteps;
+
+template <int kPattern, int kThreads>
+__global__ __launch_bounds__(kThreads) void stream_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
+                                                          uint32_t n_regions) {
+    const uint32_t tid = threadIdx.x;
+    const uint64_t total_steps = (uint64_t)n_regions * kRegionSteps;
+    constexpr uint32_t kPieces = kOutStep / 16u / kThreads;  // 16-byte stores per thread and step
+    for (uint64_t it = 0;; ++it) {
+        uint64_t step;
+        if (kPattern == 0) {
+            step = it * gridDim.x + blockIdx.x;
+        } else {
+            const uint64_t region = (it / kRegionSteps) * gridDim.x + blockIdx.x;
+            // pattern 2: the workgroups do not all stand at the same offset of their regions
+            const uint64_t turn = kPattern == 2 ? (uint64_t)blockIdx.x * 37u : 0u;
+            step = region * kRegionSteps + (it + turn) % kRegionSteps;
+        }
+        if (step >= total_steps) break;
+        const uint8_t *const src = in + step * kInStep;
+        uint8_t *const dst = out + step * kOutStep;
+        // 6 KiB: 384 pieces of 16 bytes
+        u32x4 v = {0, 0, 0, 0};
+#pragma unroll
+        for (uint32_t k = 0; k * kThreads < 384u; ++k)
+            if (tid + k * kThreads < 384u) v ^= *(const u32x4 *)(src + 16u * (tid + k * kThreads));
+#pragma unroll
+        for (uint32_t k = 0; k < kPieces; ++k) {
+            const u32x4 o = {v.x + k, v.y, v.z, v.w};
+            *(u32x4 *)(dst + 16u * (tid + kThreads * k)) = o;
+        }
+    }
+}
+
+template <int kPattern, int kThreads>
+static double run(const uint8_t *in, uint8_t *out, uint32_t regions, uint32_t grid, int reps) {
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL((stream_kernel<kPattern, kThreads>), dim3(grid), dim3(kThreads), 0, 0, in, out, regions);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0, 0));
+    for (int r = 0; r < reps; ++r)
+        hipLaunchKernelGGL((stream_kernel<kPattern, kThreads>), dim3(grid), dim3(kThreads), 0, 0, in, out, regions);
+    CHECK(hipEventRecord(e1, 0));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / reps;
+}
+
+int main(int argc, char **argv) {
+    const uint32_t regions = argc > 1 ? (uint32_t)atoi(argv[1]) : 2048u;
+    const uint32_t grid = argc > 2 ? (uint32_t)atoi(argv[2]) : 1024u;
+    const int threads = argc > 3 ? atoi(argv[3]) : 256;
+    uint8_t *in, *out;
+    CHECK(hipMalloc(&in, regions * kRegionIn));
+    CHECK(hipMalloc(&out, regions * kRegionOut));
+    CHECK(hipMemset(in, 1, regions * kRegionIn));
+    CHECK(hipMemset(out, 0, regions * kRegionOut));
+    const double bytes = (double)regions * (kRegionIn + kRegionOut);
+    for (int pattern = 0; pattern < 3; ++pattern) {
+        double ms;
+        if (threads == 256)
+            ms = pattern == 0   ? run<0, 256>(in, out, regions, grid, 10)
+                 : pattern == 1 ? run<1, 256>(in, out, regions, grid, 10)
+                                : run<2, 256>(in, out, regions, grid, 10);
+        else
+            ms = pattern == 0   ? run<0, 128>(in, out, regions, grid, 10)
+                 : pattern == 1 ? run<1, 128>(in, out, regions, grid, 10)
+                                : run<2, 128>(in, out, regions, grid, 10);
+        printf("pattern %d (%s): %u regions, %u workgroups of %d: %.3f ms, %.2f TB/s read + written (%.3f of 8 TB/s)\n", pattern,
+               pattern == 0 ? "round robin" : pattern == 1 ? "a region per workgroup" : "a region per workgroup, out of step",
+               regions, grid, threads, ms, bytes / ms * 1e-9, bytes / ms * 1e-9 / 8.0);
+    }
+    CHECK(hipFree(in));
+    CHECK(hipFree(out));
+    return 0;
+}

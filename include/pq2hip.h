@@ -89,6 +89,14 @@ int32_t pq2_ctx_enable_profiling(pq2_ctx *ctx, int32_t on);
  * "scout+expand_kernel": the same behind the scout kernels, which walk the headers of all pages in parallel over
  * tiles of the streams; "" before the first batch).  For benchmark reports. */
 const char *pq2_ctx_last_schedule(const pq2_ctx *ctx);
+/* How the batches of this context are scheduled: "auto" (the default: by the number of pages -- the scout kernels
+ * for fewer than 96, ring_kernel from there on), "scout", "ring", "tile" (parse_kernel + expand_kernel in rounds),
+ * "page" (decode_kernel).  Every schedule gives the same values and statuses; which one is fastest depends on how
+ * dense the run headers are, which the library cannot see from the descriptors: pages of very short runs (a few
+ * values each) are faster through "scout" whatever their number, pages of long runs through "ring" from about a
+ * hundred pages on.  The environment variable PQ2_MODE sets the same for every context created after it.
+ * PQ2_INVALID_PARAMETER for another name.  No counterpart in the reference. */
+int32_t pq2_ctx_set_schedule(pq2_ctx *ctx, const char *name);
 /* Diagnostics of the scout kernels: for every page of the last batch on this context, the number of rounds its
  * resolve step took until every tile of the page's stream was entered where the one before it is left (0 for a
  * page without headers to walk).  Waits for the batch.  PQ2_INVALID_PARAMETER if the last batch was not decoded

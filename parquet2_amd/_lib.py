@@ -66,6 +66,7 @@ SIGNATURES = {
     "pq2_ctx_enable_profiling": (C.c_int32, [C.c_void_p, C.c_int32]),
     "pq2_ctx_last_schedule": (C.c_char_p, [C.c_void_p]),
     "pq2_ctx_scout_rounds": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64]),
+    "pq2_ctx_set_schedule": (C.c_int32, [C.c_void_p, C.c_char_p]),
     "pq2_ctx_kernel_times": (C.c_int32, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), u64p, u64p]),
     "pq2_decode_batch_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p,
                                              C.c_uint64, C.c_void_p, C.c_void_p]),
@@ -195,6 +196,10 @@ class Context:
     def last_schedule(self):
         """Name of the kernel that carried the last batch's values."""
         return lib().pq2_ctx_last_schedule(self._h).decode()
+
+    def set_schedule(self, name):
+        """"auto" | "scout" | "ring" | "tile" | "page": how the batches of this context are scheduled."""
+        self._check(lib().pq2_ctx_set_schedule(self._h, name.encode()))
 
     def scout_rounds(self, n_pages):
         """Rounds the resolve step of the scout kernels took for every page of the last batch (diagnostics)."""

@@ -597,12 +597,7 @@ int32_t pq2_ctx_create(int32_t device_id, pq2_ctx **out) {
         if (t > 0) ctx->min_rounded_tiles = static_cast<uint64_t>(t);
     }
     if (const char *v = std::getenv("PQ2_EXPAND_STREAMS")) ctx->one_expand_stream = std::atoi(v) != 2;
-    if (const char *v = std::getenv("PQ2_MODE")) {
-        if (std::strcmp(v, "page") == 0) ctx->mode = pq2_ctx::kPerPage;
-        if (std::strcmp(v, "tile") == 0) ctx->mode = pq2_ctx::kPerTile;
-        if (std::strcmp(v, "ring") == 0) ctx->mode = pq2_ctx::kRing;
-        if (std::strcmp(v, "scout") == 0) ctx->mode = pq2_ctx::kScout;
-    }
+    if (const char *v = std::getenv("PQ2_MODE")) (void)pq2_ctx_set_schedule(ctx, v);  // another word: as without
     if (const char *v = std::getenv("PQ2_ROUND_SPLIT")) {
         double a = 0, b = 0, c = 0;
         if (std::sscanf(v, "%lf,%lf,%lf", &a, &b, &c) == 3 && 0 <= a && a <= b && b <= c && c <= 1)
@@ -617,6 +612,21 @@ int32_t pq2_ctx_create(int32_t device_id, pq2_ctx **out) {
     // table only means the entry point reports it)
     (void)pq2_noalloc_setup(device_id, nullptr);
     *out = ctx;
+    return PQ2_OK;
+}
+
+int32_t pq2_ctx_set_schedule(pq2_ctx *ctx, const char *name) {
+    if (!ctx || !name) return PQ2_INVALID_PARAMETER;
+    pq2_ctx::Mode mode;
+    if (std::strcmp(name, "auto") == 0) mode = pq2_ctx::kAuto;
+    else if (std::strcmp(name, "page") == 0) mode = pq2_ctx::kPerPage;
+    else if (std::strcmp(name, "tile") == 0) mode = pq2_ctx::kPerTile;
+    else if (std::strcmp(name, "ring") == 0) mode = pq2_ctx::kRing;
+    else if (std::strcmp(name, "scout") == 0) mode = pq2_ctx::kScout;
+    else return PQ2_INVALID_PARAMETER;
+    ctx->mode = mode;
+    for (pq2_ctx *lane : ctx->lanes)
+        if (lane) lane->mode = mode;
     return PQ2_OK;
 }
 

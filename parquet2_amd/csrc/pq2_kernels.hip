@@ -369,6 +369,10 @@ constexpr uint32_t kChunkSlots = kSpanChunks + 8u;     // ... + 2 when the outpu
 #define PQ2_STEP_GROUP 5
 #endif
 constexpr uint32_t kStepGroup = PQ2_STEP_GROUP;  // emission steps whose LDS reads are in flight together
+#ifndef PQ2_DIRECT_VALUES
+#define PQ2_DIRECT_VALUES 8
+#endif
+constexpr uint32_t kDirectValues = PQ2_DIRECT_VALUES;  // a pass whose runs are all this short is written run by run (0: never)
 
 // One wave decodes the span [block_start, block_start + block_n) of a page
 // whose width is W (block_n <= kSpanValues).  `tbl` (kTableRuns + 2 entries), `cidx` (kChunkSlots entries) and
@@ -414,6 +418,8 @@ __device__ __forceinline__ void expand_block(const __amdgpu_buffer_rsrc_t rsrc, 
     uint32_t skip = rs.skip;        // bit-packed only
     uint32_t ridx = rs.run_index;
     bool first_pass = true;
+    // header positions for the next pass, asked for as soon as the pass in hand knows where it ends
+    uint32_t ahead_at = kEndPos, ahead_hp = kEndPos;
 
     const uint32_t mis = (uint32_t)(((uintptr_t)out >> 2) & 3u);  // values between the 16-byte grid and `out`
     uint32_t lo = 0;                                               // block positions [0, lo) are written
@@ -451,26 +457,21 @@ __device__ __forceinline__ void expand_block(const __amdgpu_buffer_rsrc_t rsrc, 
                 }
             }
         } else {
-#pragma unroll
-            for (uint32_t i = 0; i < kSpanBlocks; ++i) *(u32x4 *)&cidx[4u * (lane + 64u * i)] = u32x4{0u, 0u, 0u, 0u};
-            if (lane < kChunkSlots - kSpanChunks) cidx[kSpanChunks + lane] = 0u;
             uint32_t key = kNoRun, y = 0;  // lane r: table entry r + 1
             uint32_t start = 0;            // block position of its first value
             uint32_t g = 0;                // lanes [0, g) hold usable runs
+            LaneRun run;                   // lane r: run ridx + 1 + r
+            run.kind = kRle, run.count = 0, run.info = 0;
+            bool direct = false;           // a pass of short runs: see below
             if (!alone) {
                 // lane r <- run ridx + 1 + r: position, header, length; a prefix sum places them
                 uint32_t hp = kEndPos;
-                if (first_pass)
-                    hp = hp_first;
-                else if (lane < kLaneRuns)
-                    hp = kCoh ? load_coherent(&hdrs[ridx + 1u + lane]) : hdrs[ridx + 1u + lane];
+                hp = first_pass ? hp_first : ahead_hp;
                 const uint32_t hp0 = __builtin_amdgcn_readfirstlane(hp);
                 if (hp0 != kEndPos && !win.holds(hp0 & ~3u, (hp0 & ~3u) + 24u)) {
                     if (kind == kRle) win.fill(rsrc, hp0, est, lane);  // nothing of this pass lives in the window yet
                 }
                 const bool valid = hp != kEndPos && hp >= win.lo && (hp & ~3u) + 24u <= win.hi;
-                LaneRun run;
-                run.kind = kRle, run.count = 0, run.info = 0;
                 if (valid) run = decode_lane<W>(win.lds, hp - win.lo, hp, end);
                 const uint32_t cnt = min(run.count, 2u * kSpanValues);
                 start = hi + wave_inclusive_sum(cnt) - cnt;
@@ -492,154 +493,186 @@ __device__ __forceinline__ void expand_block(const __amdgpu_buffer_rsrc_t rsrc, 
                 }
                 if (ends && lane == g && start < block_n) key = (start << 1) | kRle;  // y stays 0
                 hi = (start_g >= block_n || ends) ? block_n : start_g;
+                const bool lengthy = lane < g && start < block_n && min(run.count, block_n - start) > kDirectValues;
+                direct = take0 <= 64u && !ends && __ballot(lengthy) == 0;
+                if (hi < block_n) {  // run ridx + 1 + g will be the first run of the next pass
+                    const uint32_t *const at = &hdrs[ridx + 1u + g];
+                    ahead_at = kCoh ? load_coherent(at) : *at;
+                    ahead_hp = kEndPos;
+                    if (lane < kLaneRuns) ahead_hp = kCoh ? load_coherent(at + 1u + lane) : at[1u + lane];
+                }
             }
-            tbl[(lane + 1u) & 63u] = lane == 63u ? make_uint2((lo << 1) | kind, y0) : make_uint2(key, y);
-            // ---- index: the run that holds the first position of every chunk ---------------------------
-            if (key != kNoRun) atomicMax(&cidx[(start + mis + 3u) >> 2], lane + 1u);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            if (!alone) {
-                // lane l owns the 4 * kSpanBlocks consecutive chunks from 4 * kSpanBlocks * l on
-                u32x4 m[kSpanBlocks];
-                uint32_t run_max = 0;
+            if (direct) {
+                // ---- a pass of nothing but short runs: every lane writes its own run ---------------------------
+                // No run of the pass has more than kDirectValues values (pages of very short runs: one pass covers
+                // a few hundred values, and the table, the chunk index and the steps over a whole span would cost
+                // more than the values).  The first run's values go one to a lane.
+                if (lane < take0) {
+                    const uint32_t p0 = lo + lane;
+                    out[p0] = kind == kRle ? payload : field_at<W>(win.lds, (y0 + p0 * w) & bit_mask);
+                }
+                if (lane < g && start < block_n) {
+                    const uint32_t mine = min(run.count, block_n - start);
+                    const uint32_t bit0 = run.kind == kBitpacked ? (run.info - win.lo) * 8u : 0u;
+                    uint32_t f[kDirectValues];
 #pragma unroll
-                for (uint32_t i = 0; i < kSpanBlocks; ++i) {
-                    m[i] = *(const u32x4 *)&cidx[4u * (kSpanBlocks * lane + i)];
-                    m[i].x = max(m[i].x, run_max);
-                    m[i].y = max(m[i].x, m[i].y);
-                    m[i].z = max(m[i].y, m[i].z);
-                    m[i].w = max(m[i].z, m[i].w);
-                    run_max = m[i].w;
-                }
-                const uint32_t upto = wave_inclusive_max(run_max);
-                const uint32_t before = __builtin_amdgcn_update_dpp(0u, upto, 0x138, 0xf, 0xf, false);  // wave_shr:1
+                    for (uint32_t k = 0; k < kDirectValues; ++k) f[k] = field_at<W>(win.lds, (bit0 + k * w) & bit_mask);
 #pragma unroll
-                for (uint32_t i = 0; i < kSpanBlocks; ++i) {
-                    m[i].x = max(m[i].x, before), m[i].y = max(m[i].y, before);
-                    m[i].z = max(m[i].z, before), m[i].w = max(m[i].w, before);
-                    *(u32x4 *)&cidx[4u * (kSpanBlocks * lane + i)] = m[i];
+                    for (uint32_t k = 0; k < kDirectValues; ++k)
+                        if (k < mine) out[start + k] = run.kind == kRle ? run.info : f[k];
                 }
-                if (lane == 63u) {  // two more chunks exist when the output is not 16-byte aligned
-                    const uint32_t c0 = max(upto, cidx[kSpanChunks]);
-                    cidx[kSpanChunks] = c0;
-                    cidx[kSpanChunks + 1u] = max(c0, cidx[kSpanChunks + 1u]);
-                }
+            } else {
+#pragma unroll
+                for (uint32_t i = 0; i < kSpanBlocks; ++i) *(u32x4 *)&cidx[4u * (lane + 64u * i)] = u32x4{0u, 0u, 0u, 0u};
+                if (lane < kChunkSlots - kSpanChunks) cidx[kSpanChunks + lane] = 0u;
+                tbl[(lane + 1u) & 63u] = lane == 63u ? make_uint2((lo << 1) | kind, y0) : make_uint2(key, y);
+                // ---- index: the run that holds the first position of every chunk ---------------------------
+                if (key != kNoRun) atomicMax(&cidx[(start + mis + 3u) >> 2], lane + 1u);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-            }
+                if (!alone) {
+                    // lane l owns the 4 * kSpanBlocks consecutive chunks from 4 * kSpanBlocks * l on
+                    u32x4 m[kSpanBlocks];
+                    uint32_t run_max = 0;
+#pragma unroll
+                    for (uint32_t i = 0; i < kSpanBlocks; ++i) {
+                        m[i] = *(const u32x4 *)&cidx[4u * (kSpanBlocks * lane + i)];
+                        m[i].x = max(m[i].x, run_max);
+                        m[i].y = max(m[i].x, m[i].y);
+                        m[i].z = max(m[i].y, m[i].z);
+                        m[i].w = max(m[i].z, m[i].w);
+                        run_max = m[i].w;
+                    }
+                    const uint32_t upto = wave_inclusive_max(run_max);
+                    const uint32_t before = __builtin_amdgcn_update_dpp(0u, upto, 0x138, 0xf, 0xf, false);  // wave_shr:1
+#pragma unroll
+                    for (uint32_t i = 0; i < kSpanBlocks; ++i) {
+                        m[i].x = max(m[i].x, before), m[i].y = max(m[i].y, before);
+                        m[i].z = max(m[i].z, before), m[i].w = max(m[i].w, before);
+                        *(u32x4 *)&cidx[4u * (kSpanBlocks * lane + i)] = m[i];
+                    }
+                    if (lane == 63u) {  // two more chunks exist when the output is not 16-byte aligned
+                        const uint32_t c0 = max(upto, cidx[kSpanChunks]);
+                        cidx[kSpanChunks] = c0;
+                        cidx[kSpanChunks + 1u] = max(c0, cidx[kSpanChunks + 1u]);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
 
-            // ---- phase 2: one chunk per lane and step ---------------------------------------------------
-            // The steps do not depend on each other and there are at most 4 * kSpanBlocks + 1 of them (one more
-            // than the chunks of a span when the output is not 16-byte aligned).  Every step is a chain of three
-            // dependent LDS reads (chunk index -> table entry -> stream dwords); the steps are taken in groups
-            // whose reads of one kind are issued together and waited for once (`pin` keeps the compiler from
-            // sinking a read into the branch that uses it, which would serialise the chains).
-            const uint32_t q_end = (hi + mis + 3u) >> 2;
-            const uint32_t q_first = ((lo + mis) >> 2) + lane;
-            bool ragged = false;  // some lane holds the first or last chunk of the span, and not all of it
-            constexpr uint32_t kSteps = 4u * kSpanBlocks + 1u;
+                // ---- phase 2: one chunk per lane and step ---------------------------------------------------
+                // The steps do not depend on each other and there are at most 4 * kSpanBlocks + 1 of them (one more
+                // than the chunks of a span when the output is not 16-byte aligned).  Every step is a chain of three
+                // dependent LDS reads (chunk index -> table entry -> stream dwords); the steps are taken in groups
+                // whose reads of one kind are issued together and waited for once (`pin` keeps the compiler from
+                // sinking a read into the branch that uses it, which would serialise the chains).
+                const uint32_t q_end = (hi + mis + 3u) >> 2;
+                const uint32_t q_first = ((lo + mis) >> 2) + lane;
+                bool ragged = false;  // some lane holds the first or last chunk of the span, and not all of it
+                constexpr uint32_t kSteps = 4u * kSpanBlocks + 1u;
 #pragma unroll
-            for (uint32_t g0 = 0; g0 < kSteps; g0 += kStepGroup) {
-                if (((lo + mis) >> 2) + 64u * g0 >= q_end) break;  // a pass of few short runs ends early
-                uint32_t j[kStepGroup];
+                for (uint32_t g0 = 0; g0 < kSteps; g0 += kStepGroup) {
+                    if (((lo + mis) >> 2) + 64u * g0 >= q_end) break;  // a pass of few short runs ends early
+                    uint32_t j[kStepGroup];
 #pragma unroll
-                for (uint32_t i = 0; i < kStepGroup; ++i)
-                    if (g0 + i < kSteps) j[i] = cidx[min(q_first + 64u * (g0 + i), kChunkSlots - 1u)];
+                    for (uint32_t i = 0; i < kStepGroup; ++i)
+                        if (g0 + i < kSteps) j[i] = cidx[min(q_first + 64u * (g0 + i), kChunkSlots - 1u)];
 #pragma unroll
-                for (uint32_t i = 0; i < kStepGroup; ++i)
-                    if (g0 + i < kSteps) pin(j[i]);
-                // the entry and the key of the next one (two naturally aligned reads: a 16-byte read at an
-                // 8-byte boundary would be replayed)
-                uint2 e[kStepGroup];
-                uint32_t nxt[kStepGroup];
+                    for (uint32_t i = 0; i < kStepGroup; ++i)
+                        if (g0 + i < kSteps) pin(j[i]);
+                    // the entry and the key of the next one (two naturally aligned reads: a 16-byte read at an
+                    // 8-byte boundary would be replayed)
+                    uint2 e[kStepGroup];
+                    uint32_t nxt[kStepGroup];
 #pragma unroll
-                for (uint32_t i = 0; i < kStepGroup; ++i)
-                    if (g0 + i < kSteps) e[i] = tbl[j[i]], nxt[i] = tbl[j[i] + 1u].x;
+                    for (uint32_t i = 0; i < kStepGroup; ++i)
+                        if (g0 + i < kSteps) e[i] = tbl[j[i]], nxt[i] = tbl[j[i] + 1u].x;
 #pragma unroll
-                for (uint32_t i = 0; i < kStepGroup; ++i)
-                    if (g0 + i < kSteps) pin(e[i].x), pin(e[i].y), pin(nxt[i]);
-                FieldWords<W> x[kStepGroup];
+                    for (uint32_t i = 0; i < kStepGroup; ++i)
+                        if (g0 + i < kSteps) pin(e[i].x), pin(e[i].y), pin(nxt[i]);
+                    FieldWords<W> x[kStepGroup];
 #pragma unroll
-                for (uint32_t i = 0; i < kStepGroup; ++i)
-                    if (g0 + i < kSteps) {
-                        const int32_t p = (int32_t)((q_first + 64u * (g0 + i)) * 4u) - (int32_t)mis;
-                        x[i] = load_fields<W>(win.lds, (e[i].y + (uint32_t)p * w) & bit_mask);
-                    }
+                    for (uint32_t i = 0; i < kStepGroup; ++i)
+                        if (g0 + i < kSteps) {
+                            const int32_t p = (int32_t)((q_first + 64u * (g0 + i)) * 4u) - (int32_t)mis;
+                            x[i] = load_fields<W>(win.lds, (e[i].y + (uint32_t)p * w) & bit_mask);
+                        }
 #pragma unroll
-                for (uint32_t i = 0; i < kStepGroup; ++i)
-                    if (g0 + i < kSteps) x[i].pin_all();
+                    for (uint32_t i = 0; i < kStepGroup; ++i)
+                        if (g0 + i < kSteps) x[i].pin_all();
 #pragma unroll
-                for (uint32_t i = 0; i < kStepGroup; ++i)
-                    if (g0 + i < kSteps) {
-                        const uint32_t q = q_first + 64u * (g0 + i);
-                        const bool active = q < q_end;
+                    for (uint32_t i = 0; i < kStepGroup; ++i)
+                        if (g0 + i < kSteps) {
+                            const uint32_t q = q_first + 64u * (g0 + i);
+                            const bool active = q < q_end;
+                            const int32_t p = (int32_t)(q * 4u) - (int32_t)mis;
+                            // no run starts behind the chunk's first position
+                            const bool single = active & (((((uint32_t)(p + 3)) << 1) | 1u) < nxt[i]);
+                            const bool full = (p >= (int32_t)lo) & (p + 4 <= (int32_t)hi);
+                            const u32x4 f = x[i].fields4();
+                            const bool rle = (e[i].x & 1u) != 0u;
+                            const uint32_t r = e[i].y;
+                            const u32x4 v = {rle ? r : f.x, rle ? r : f.y, rle ? r : f.z, rle ? r : f.w};
+                            if (single & full) store4(v, out + p);
+                            ragged = ragged | (single & !full);
+                        }
+                }
+                if (__builtin_expect(__ballot(ragged) != 0, 0)) {
+                    // the first and the last chunk of the span, where they lie inside one run: position by position
+#pragma unroll
+                    for (uint32_t side = 0; side < 2u; ++side) {
+                        const uint32_t q = side == 0 ? (lo + mis) >> 2 : q_end - 1u;
                         const int32_t p = (int32_t)(q * 4u) - (int32_t)mis;
-                        // no run starts behind the chunk's first position
-                        const bool single = active & (((((uint32_t)(p + 3)) << 1) | 1u) < nxt[i]);
-                        const bool full = (p >= (int32_t)lo) & (p + 4 <= (int32_t)hi);
-                        const u32x4 f = x[i].fields4();
-                        const bool rle = (e[i].x & 1u) != 0u;
-                        const uint32_t r = e[i].y;
-                        const u32x4 v = {rle ? r : f.x, rle ? r : f.y, rle ? r : f.z, rle ? r : f.w};
-                        if (single & full) store4(v, out + p);
-                        ragged = ragged | (single & !full);
+                        const int32_t pos = p + (int32_t)(lane & 3u);
+                        const uint32_t j = cidx[q];
+                        const uint2 e = tbl[j];
+                        const uint32_t nxt = tbl[j + 1u].x;
+                        const bool single = ((((uint32_t)(p + 3)) << 1) | 1u) < nxt;
+                        const bool full = p >= (int32_t)lo && p + 4 <= (int32_t)hi;
+                        const uint32_t f = field_at<W>(win.lds, (e.y + (uint32_t)pos * w) & bit_mask);
+                        if (lane < 4u && single && !full && pos >= (int32_t)lo && pos < (int32_t)hi)
+                            out[pos] = (e.x & 1u) ? e.y : f;
                     }
-            }
-            if (__builtin_expect(__ballot(ragged) != 0, 0)) {
-                // the first and the last chunk of the span, where they lie inside one run: position by position
-#pragma unroll
-                for (uint32_t side = 0; side < 2u; ++side) {
-                    const uint32_t q = side == 0 ? (lo + mis) >> 2 : q_end - 1u;
+                }
+                // the chunks in which a run starts: lane r takes the one of run r + 1, value by value.  The chunk's
+                // four positions lie in the run that holds its first position and the up to three behind it (runs in
+                // the table hold at least one value); their entries are read together, then the four fields.
+                if (key != kNoRun) {
+                    const uint32_t q = (start + mis) >> 2;
                     const int32_t p = (int32_t)(q * 4u) - (int32_t)mis;
-                    const int32_t pos = p + (int32_t)(lane & 3u);
-                    const uint32_t j = cidx[q];
-                    const uint2 e = tbl[j];
-                    const uint32_t nxt = tbl[j + 1u].x;
-                    const bool single = ((((uint32_t)(p + 3)) << 1) | 1u) < nxt;
-                    const bool full = p >= (int32_t)lo && p + 4 <= (int32_t)hi;
-                    const uint32_t f = field_at<W>(win.lds, (e.y + (uint32_t)pos * w) & bit_mask);
-                    if (lane < 4u && single && !full && pos >= (int32_t)lo && pos < (int32_t)hi)
-                        out[pos] = (e.x & 1u) ? e.y : f;
-                }
-            }
-            // the chunks in which a run starts: lane r takes the one of run r + 1, value by value.  The chunk's
-            // four positions lie in the run that holds its first position and the up to three behind it (runs in
-            // the table hold at least one value); their entries are read together, then the four fields.
-            if (key != kNoRun) {
-                const uint32_t q = (start + mis) >> 2;
-                const int32_t p = (int32_t)(q * 4u) - (int32_t)mis;
-                const uint32_t j0 = cidx[q];
-                uint2 t[5];  // entries j0 .. j0 + 4 (behind the table's end: the sentinel)
+                    const uint32_t j0 = cidx[q];
+                    uint2 t[5];  // entries j0 .. j0 + 4 (behind the table's end: the sentinel)
 #pragma unroll
-                for (uint32_t i = 0; i < 5u; ++i) t[i] = tbl[min(j0 + i, kTableRuns + 1u)];
+                    for (uint32_t i = 0; i < 5u; ++i) t[i] = tbl[min(j0 + i, kTableRuns + 1u)];
 #pragma unroll
-                for (uint32_t i = 0; i < 5u; ++i) pin(t[i].x), pin(t[i].y);
-                uint2 cur[4];
+                    for (uint32_t i = 0; i < 5u; ++i) pin(t[i].x), pin(t[i].y);
+                    uint2 cur[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const uint32_t pk = (uint32_t)max(p + k, (int32_t)lo);
-                    if (((pk << 1) | 1u) >= t[1].x) {  // one step forward is enough: the window moves up
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t pk = (uint32_t)max(p + k, (int32_t)lo);
+                        if (((pk << 1) | 1u) >= t[1].x) {  // one step forward is enough: the window moves up
 #pragma unroll
-                        for (uint32_t i = 0; i < 4u; ++i) t[i] = t[i + 1u];
+                            for (uint32_t i = 0; i < 4u; ++i) t[i] = t[i + 1u];
+                        }
+                        cur[k] = t[0];
                     }
-                    cur[k] = t[0];
+                    uint32_t f[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t pk = (uint32_t)max(p + k, (int32_t)lo);
+                        f[k] = field_at<W>(win.lds, (cur[k].y + pk * w) & bit_mask);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) pin(f[k]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (p + k >= (int32_t)lo && p + k < (int32_t)hi) out[p + k] = (cur[k].x & 1u) ? cur[k].y : f[k];
                 }
-                uint32_t f[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const uint32_t pk = (uint32_t)max(p + k, (int32_t)lo);
-                    f[k] = field_at<W>(win.lds, (cur[k].y + pk * w) & bit_mask);
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) pin(f[k]);
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (p + k >= (int32_t)lo && p + k < (int32_t)hi) out[p + k] = (cur[k].x & 1u) ? cur[k].y : f[k];
             }
             // ---- next pass (rare: more than 63 runs in the block, or bytes beyond the window) --------------
             if (hi < block_n && !alone) {  // run ridx + 1 + g becomes the first run
                 ridx += 1u + g;
-                const uint32_t at = __builtin_amdgcn_readfirstlane(kCoh ? load_coherent(&hdrs[ridx]) : hdrs[ridx]);
+                const uint32_t at = __builtin_amdgcn_readfirstlane(ahead_at);
                 if (!win.holds(at & ~3u, (at & ~3u) + 24u)) win.fill(rsrc, at, (((block_n - hi) * w) >> 3) + 64u, lane);
                 auto rd = [&](uint32_t a) -> uint32_t { return __builtin_amdgcn_readfirstlane(win.dword(a)); };
                 const RunInfo run = decode_run(rd, at, end, w, n - (block_start + hi));

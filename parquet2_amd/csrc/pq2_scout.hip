@@ -103,18 +103,6 @@ __device__ __forceinline__ bool scout_page_done(const ParseState *__restrict__ s
 }
 
 // ---------------------------------------------------------------------------
-// map: which page a stream tile belongs to
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void scout_map_kernel(const ScoutPage *__restrict__ sp, uint32_t n_pages,
-                                                        uint32_t *__restrict__ tiles, uint32_t n_stiles) {
-    const uint32_t page = blockIdx.x;
-    if (page >= n_pages) return;
-    const ScoutPage s = sp[page];
-    const ScoutTiles t = scout_tiles(tiles, n_stiles);
-    for (uint32_t k = threadIdx.x; k < s.n_tiles; k += 256u) t.page[s.tile_base + k] = page;
-}
-
-// ---------------------------------------------------------------------------
 // table
 // ---------------------------------------------------------------------------
 // The bytes of a lane's segment and the first four behind it (what a header in the segment's last byte may need).
@@ -171,9 +159,9 @@ __device__ __forceinline__ void scout_segments(const SegBytes &sb, const uint32_
 
 // One wave per tile, four tiles per workgroup.
 __global__ __launch_bounds__(256) void scout_table_kernel(const PageDev *__restrict__ pages,
-                                                          const ScoutPage *__restrict__ sp, uint32_t *__restrict__ tiles,
-                                                          uint16_t *__restrict__ table, uint32_t n_stiles,
-                                                          const ParseState *__restrict__ state,
+                                                          const ScoutPage *__restrict__ sp, uint32_t n_pages,
+                                                          uint32_t *__restrict__ tiles, uint16_t *__restrict__ table,
+                                                          uint32_t n_stiles, const ParseState *__restrict__ state,
                                                           uint32_t *__restrict__ hints) {
     __shared__ __attribute__((aligned(16))) uint16_t lds[4][kScoutTable];
     __shared__ uint32_t votes[4][kScoutBins / 2u];  // two 16-bit counters per word
@@ -182,7 +170,14 @@ __global__ __launch_bounds__(256) void scout_table_kernel(const PageDev *__restr
     const uint32_t g = blockIdx.x * 4u + wave;
     if (g >= n_stiles) return;
     const ScoutTiles t = scout_tiles(tiles, n_stiles);
-    const uint32_t page = __builtin_amdgcn_readfirstlane(t.page[g]);
+    // the page this tile belongs to: the last one whose first tile is not behind g (a page without tiles has the
+    // first tile of the page behind it, and comes before it); noted for the steps that follow
+    uint32_t page = 0;
+    for (uint32_t step = 1u << (31u - (uint32_t)__builtin_clz(n_pages)); step != 0u; step >>= 1) {
+        const uint32_t p = page + step;
+        if (p < n_pages && __builtin_amdgcn_readfirstlane(sp[p].tile_base) <= g) page = p;
+    }
+    if (lane == 0) t.page[g] = page;
     if (scout_page_done(state, page)) return;
     const PageDev pg = pages[page];
     const uint32_t t0 = (g - __builtin_amdgcn_readfirstlane(sp[page].tile_base)) * kScoutTile;
@@ -960,9 +955,8 @@ extern "C" hipError_t pq2_launch_scout(const void *pages, const void *spages, ui
     uint16_t *tbl = (uint16_t *)table;
     const uint32_t tile_groups = (n_stiles + 3u) / 4u;
     if (n_stiles != 0u) {
-        hipLaunchKernelGGL(scout_map_kernel, dim3(n_pages), dim3(256), 0, stream, sp, n_pages, tiles, n_stiles);
-        hipLaunchKernelGGL(scout_table_kernel, dim3(tile_groups), dim3(256), 0, stream, pg, sp, tiles, tbl, n_stiles, done,
-                           hints);
+        hipLaunchKernelGGL(scout_table_kernel, dim3(tile_groups), dim3(256), 0, stream, pg, sp, n_pages, tiles, tbl, n_stiles,
+                           done, hints);
         constexpr uint32_t kResolveLds = kScoutResolveArrays * (kScoutLdsTiles + 8u) * 4u;  // above the 64 KiB a kernel gets unasked
         e = hipFuncSetAttribute((const void *)scout_resolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kResolveLds);
         if (e != hipSuccess) return e;

@@ -253,3 +253,28 @@ def test_sparse_headers_at_several_widths(scout, oracle):
     check_batch(scout, oracle, pages)
     rounds = scout.scout_rounds(len(pages))
     assert rounds.min() >= 1 and rounds[:4].max() <= 4, rounds
+
+
+def test_schedule_chosen_by_the_caller(oracle):
+    """pq2_ctx_set_schedule: the same batch through every schedule on one context, and back to the default (which
+    takes the scout kernels for 8 pages); a name the library does not know is refused."""
+    from parquet2_amd import Context
+    from parquet2_amd.error import InvalidParameter
+
+    pages = []
+    for k in range(8):
+        stream, _ = synth.adversarial(synth.seed_for(4, 900 + k), 50_000, 5)
+        pages.append((stream, 5, 50_000))
+    ctx = Context(0)
+    try:
+        for name, kernel in (("ring", "ring_kernel"), ("scout", "scout+expand_kernel"), ("tile", "expand_kernel"),
+                             ("page", "decode_kernel"), ("auto", "scout+expand_kernel")):
+            ctx.set_schedule(name)
+            check_batch(ctx, oracle, pages, msg=name)
+            assert ctx.last_schedule() == kernel, (name, ctx.last_schedule())
+        with pytest.raises(InvalidParameter):
+            ctx.set_schedule("fastest")
+        check_batch(ctx, oracle, pages)
+        assert ctx.last_schedule() == "scout+expand_kernel"
+    finally:
+        ctx.close()

@@ -11,7 +11,8 @@
 //            results in LDS); a pass over the segments from the last to the first then extends every entry to the
 //            end of the tile.  Everything unusual (a varint of three or more bytes, a run that passes the end of
 //            the stream or reaches further than 32 KiB from the tile) is an escape that names the header, which
-//            is then decoded exactly by whoever gets there.  2 bytes per stream byte, written once.
+//            is then decoded exactly by whoever gets there.  2 bytes per stream byte, written once (and 2 more for
+//            the table before the pass over the segments, which the count step uses).
 //            It also counts, per tile, at which offsets of the next tile most of its chains arrive (votes): the
 //            four strongest are handed on as guesses of where the page's chain enters that tile.
 //   resolve  one workgroup per page.  First the votes are carried forward from tile to tile through the tables
@@ -189,6 +190,17 @@ __global__ __launch_bounds__(256) void scout_table_kernel(const PageDev *__restr
         scout_segments(scout_load_segment(rsrc, t0 + lane * kScoutSeg), t0, end, pg.num_bits, tbl, lane);
     }
     wave_sync();
+    // the table as it is now -- where every chain leaves its SEGMENT -- is what the count step walks a tile of many
+    // headers with: a copy goes behind the tables proper (tile g's at table + (n_stiles + g) * kScoutTable)
+    {
+        u32x4 *const dst = (u32x4 *)(table + ((size_t)n_stiles + g) * kScoutTable);
+        const u32x4 *const src = (const u32x4 *)tbl;
+#pragma unroll
+        for (uint32_t i = 0; i < 5; ++i) {
+            const uint32_t at = i * 64u + lane;
+            if (at < kScoutTable * 2u / 16u) dst[at] = src[at];
+        }
+    }
     // An entry that leaves its segment inside the tile takes over the entry of the offset it lands on, once that
     // one is final.  In two levels, so that all lanes work: first inside every group of 8 segments, from each group's
     // last segment but one to its first (all 8 groups at a time: 256 entries a step), then group by group from the
@@ -605,7 +617,7 @@ __global__ __launch_bounds__(256) void scout_count_kernel(const PageDev *__restr
 
     uint32_t vals = 0, listed = 0, term = 0;
     // ---- a tile with many headers: all lanes at once --------------------------------------------------------
-    // Lane l finds, as the table step does, where the chains inside segment l lead; one walk from segment to
+    // The table step has kept where the chains inside every segment lead; one walk from segment to
     // segment (at most 64 steps instead of one per header) then tells every segment where the page's chain
     // enters it, and each lane follows the chain through its own 32 bytes.  At the first header the table step
     // would leave to the exact decoder (the end of the stream is one) the walk below takes over.
@@ -614,7 +626,21 @@ __global__ __launch_bounds__(256) void scout_count_kernel(const PageDev *__restr
     if (__builtin_amdgcn_readfirstlane(tl.vals[g]) >= kScoutDense || tile_end >= end) {
         uint16_t *const tbl = seg_lds[wave];
         const SegBytes sb = scout_load_segment(rsrc, t0 + lane * kScoutSeg);
-        scout_segments(sb, t0, end, w, tbl, lane);
+        {  // the per-segment table, as the table step left it
+            const u32x4 *const src = (const u32x4 *)(table + ((size_t)n_stiles + g) * kScoutTable);
+            u32x4 *const dst = (u32x4 *)tbl;
+            u32x4 piece[5];
+#pragma unroll
+            for (uint32_t i = 0; i < 5; ++i) {
+                const uint32_t at = i * 64u + lane;
+                if (at < kScoutTable * 2u / 16u) piece[i] = src[at];
+            }
+#pragma unroll
+            for (uint32_t i = 0; i < 5; ++i) {
+                const uint32_t at = i * 64u + lane;
+                if (at < kScoutTable * 2u / 16u) dst[at] = piece[i];
+            }
+        }
         wave_sync();
         uint32_t x = pos - t0, mine = kScoutSeg;  // mine: the offset at which the chain enters this lane's segment
         uint32_t stop = kScoutSeg;                // ... and the offset of its segment from which the lane keeps out
@@ -918,7 +944,8 @@ __global__ __launch_bounds__(256) void scout_place_kernel(const PageDev *__restr
 // Bytes of device memory the scout kernels need for a batch with `n_stiles` stream tiles in `n_pages` pages:
 // the tables, the per-tile words, the per-page closing records and the resolve step's arrays for large pages.
 extern "C" uint32_t pq2_scout_tile_bytes() { return pq2::kScoutTile; }
-extern "C" size_t pq2_scout_table_bytes(uint64_t n_stiles) { return (size_t)n_stiles * pq2::kScoutTable * 2u; }
+// (two tables per tile: where the chains leave the tile, and where they leave their segments)
+extern "C" size_t pq2_scout_table_bytes(uint64_t n_stiles) { return 2u * (size_t)n_stiles * pq2::kScoutTable * 2u; }
 // where, in `words`, the resolve step leaves the number of rounds it took for every page (diagnostics)
 extern "C" size_t pq2_scout_rounds_at(uint64_t n_stiles, uint64_t n_pages) { return (7u * (size_t)n_stiles + 2u * (size_t)n_pages) * 4u; }
 extern "C" size_t pq2_scout_words_bytes(uint64_t n_stiles, uint64_t n_pages) {

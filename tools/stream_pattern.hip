@@ -29,7 +29,7 @@ constexpr uint32_t kOutStep = 16384, kInStep = 6144;        // bytes per workgro
 constexpr uint32_t kRegionSteps = 256;                      // steps per region: 4 MiB written
 constexpr uint64_t kRegionOut = (uint64_t)kOutStep * kRegionSteps, kRegionIn = (uint64_t)kInStep * kRegionSteps;
 
-template <int kPattern, int kThreads>
+template <int kPattern, int kThreads, bool kNt = false>
 __global__ __launch_bounds__(kThreads) void stream_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
                                                           uint32_t n_regions) {
     const uint32_t tid = threadIdx.x;
@@ -56,21 +56,24 @@ __global__ __launch_bounds__(kThreads) void stream_kernel(const uint8_t *__restr
 #pragma unroll
         for (uint32_t k = 0; k < kPieces; ++k) {
             const u32x4 o = {v.x + k, v.y, v.z, v.w};
-            *(u32x4 *)(dst + 16u * (tid + kThreads * k)) = o;
+            if (kNt)
+                __builtin_nontemporal_store(o, (u32x4 *)(dst + 16u * (tid + kThreads * k)));
+            else
+                *(u32x4 *)(dst + 16u * (tid + kThreads * k)) = o;
         }
     }
 }
 
-template <int kPattern, int kThreads>
+template <int kPattern, int kThreads, bool kNt = false>
 static double run(const uint8_t *in, uint8_t *out, uint32_t regions, uint32_t grid, int reps) {
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
-    hipLaunchKernelGGL((stream_kernel<kPattern, kThreads>), dim3(grid), dim3(kThreads), 0, 0, in, out, regions);
+    hipLaunchKernelGGL((stream_kernel<kPattern, kThreads, kNt>), dim3(grid), dim3(kThreads), 0, 0, in, out, regions);
     CHECK(hipDeviceSynchronize());
     CHECK(hipEventRecord(e0, 0));
     for (int r = 0; r < reps; ++r)
-        hipLaunchKernelGGL((stream_kernel<kPattern, kThreads>), dim3(grid), dim3(kThreads), 0, 0, in, out, regions);
+        hipLaunchKernelGGL((stream_kernel<kPattern, kThreads, kNt>), dim3(grid), dim3(kThreads), 0, 0, in, out, regions);
     CHECK(hipEventRecord(e1, 0));
     CHECK(hipEventSynchronize(e1));
     float ms = 0;
@@ -101,6 +104,34 @@ int main(int argc, char **argv) {
         printf("pattern %d (%s): %u regions, %u workgroups of %d: %.3f ms, %.2f TB/s read + written (%.3f of 8 TB/s)\n", pattern,
                pattern == 0 ? "round robin" : pattern == 1 ? "a region per workgroup" : "a region per workgroup, out of step",
                regions, grid, threads, ms, bytes / ms * 1e-9, bytes / ms * 1e-9 / 8.0);
+    }
+    if (threads == 256) {  // the same with stores marked as not to be read again soon
+        const double a = run<0, 256, true>(in, out, regions, grid, 10), b = run<1, 256, true>(in, out, regions, grid, 10);
+        printf("nontemporal stores: round robin %.3f ms (%.3f of 8 TB/s), a region per workgroup %.3f ms (%.3f)\n", a,
+               bytes / a * 1e-9 / 8.0, b, bytes / b * 1e-9 / 8.0);
+    }
+    // what the two directions give alone: the same grid reading / writing 8 GiB
+    {
+        hipEvent_t e0, e1;
+        CHECK(hipEventCreate(&e0));
+        CHECK(hipEventCreate(&e1));
+        const double gib8 = (double)regions * kRegionOut;
+        for (int dir = 0; dir < 2; ++dir) {
+            CHECK(hipEventRecord(e0, 0));
+            for (int r = 0; r < 5; ++r) {
+                if (dir == 0)
+                    CHECK(hipMemsetAsync(out, r, regions * kRegionOut, 0));
+                else
+                    CHECK(hipMemcpyAsync(out, out + regions * kRegionOut / 2, regions * kRegionOut / 2, hipMemcpyDeviceToDevice, 0));
+            }
+            CHECK(hipEventRecord(e1, 0));
+            CHECK(hipEventSynchronize(e1));
+            float ms = 0;
+            CHECK(hipEventElapsedTime(&ms, e0, e1));
+            ms /= 5;
+            printf("%s of %.1f GB: %.3f ms, %.2f TB/s%s\n", dir == 0 ? "hipMemsetAsync" : "hipMemcpyAsync (half onto half)",
+                   gib8 * 1e-9, ms, gib8 / ms * 1e-9, dir == 0 ? " written" : " read + written");
+        }
     }
     CHECK(hipFree(in));
     CHECK(hipFree(out));

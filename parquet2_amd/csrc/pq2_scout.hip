@@ -51,10 +51,6 @@ constexpr uint32_t kScoutWin = kScoutTile + 64u;            // bytes of a tile t
 constexpr uint32_t kScoutPanic = 0x80000000u, kScoutTerm = 0x40000000u, kScoutBad = 0x20000000u;
 constexpr uint32_t kScoutRunsMask = 0x1fffffffu;
 constexpr uint32_t kValueCap = 0x7fffffffu;
-#ifndef PQ2_SCOUT_BINS
-#define PQ2_SCOUT_BINS 1024
-#endif
-constexpr uint32_t kScoutBins = PQ2_SCOUT_BINS;             // vote counters per tile (exits that far apart share one)
 #ifndef PQ2_SCOUT_VOTERS
 #define PQ2_SCOUT_VOTERS 64
 #endif
@@ -65,13 +61,13 @@ constexpr uint32_t kScoutVoters = PQ2_SCOUT_VOTERS;         // the offsets of th
 constexpr uint32_t kScoutDense = PQ2_SCOUT_DENSE;           // headers per tile from which the count step works lane-parallel
 constexpr uint32_t kScoutKeep = 4;                          // exits of a tile the table step hands on, most voted first
 constexpr uint32_t kScoutResolveThreads = 1024;             // threads of the resolve step's one workgroup per page
+constexpr uint32_t kScoutScanThreads = 1024;                // threads of the scan step's one workgroup per page
 constexpr uint32_t kScoutResolveArrays = 12;                // arrays of kScoutLdsTiles + 8 words it keeps in LDS
 constexpr uint32_t kScoutSure = 96;                         // votes (of 2048) from which the first exit is handed on alone
 #ifndef PQ2_SCOUT_PUSHES
 #define PQ2_SCOUT_PUSHES 12
 #endif
 constexpr uint32_t kScoutPushes = PQ2_SCOUT_PUSHES;         // tiles a vote is carried forward at most (resolve step)
-static_assert(kScoutBins * 2u == kScoutTile, "two exits share a vote counter: one in either half of the next tile");
 
 struct ScoutPage {
     uint32_t tile_base;  // batch-wide number of the page's first stream tile
@@ -165,7 +161,6 @@ __global__ __launch_bounds__(256) void scout_table_kernel(const PageDev *__restr
                                                           uint32_t n_stiles, const ParseState *__restrict__ state,
                                                           uint32_t *__restrict__ hints) {
     __shared__ __attribute__((aligned(16))) uint16_t lds[4][kScoutTable];
-    __shared__ uint32_t votes[4][kScoutBins / 2u];  // two 16-bit counters per word
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t g = blockIdx.x * 4u + wave;
@@ -226,28 +221,43 @@ __global__ __launch_bounds__(256) void scout_table_kernel(const PageDev *__restr
         }
         wave_sync();
     }
+    // the table as it lies in LDS: kScoutTable * 2 = 4224 bytes = 264 pieces of 16
+    {
+        u32x4 *const dst = (u32x4 *)(table + (size_t)g * kScoutTable);
+        const u32x4 *const src = (const u32x4 *)tbl;
+#pragma unroll
+        for (uint32_t i = 0; i < 5; ++i) {
+            const uint32_t at = i * 64u + lane;
+            if (at < kScoutTable * 2u / 16u) dst[at] = src[at];
+        }
+    }
     // Guesses at where the page's chain enters the next tile: the offsets there at which most of this tile's chains
     // arrive.  Every header of the page's chain inside this tile is an offset that votes for the true one, while
     // the chains that start inside bit-packed payloads scatter -- but they gather too (a few dozen offsets of random
     // bytes may lead to one place), so where headers are sparse the true exit is often not the first but among the
     // first few: kScoutKeep of them are handed on with their votes.  (Only guesses: the resolve step decides.)
+    // The votes are counted where the table lay: one 16-bit counter for each offset of the next tile.
     {
-        uint32_t *const vote = votes[wave];
+        static_assert(kScoutTable * 2u >= kScoutTile * 2u && kScoutSeg == 32u, "the counters fit the table's LDS");
+        uint32_t ent[kScoutSeg / 2u];  // this lane's 32 entries (the offsets of segment `lane`), two to a register
 #pragma unroll
-        for (uint32_t i = 0; i < kScoutBins / 2u / 64u; ++i) vote[i * 64u + lane] = 0u;
+        for (uint32_t i = 0; i < kScoutSeg / 2u; ++i)
+            ent[i] = (uint32_t)tbl[2u * i * kScoutRow + lane] | ((uint32_t)tbl[(2u * i + 1u) * kScoutRow + lane] << 16);
+        wave_sync();
+        uint32_t *const vote = (uint32_t *)tbl;  // counter of offset x: half x & 1 of word x >> 1
+#pragma unroll
+        for (uint32_t i = 0; i < kScoutTile / 2u / 4u / 64u; ++i) *(u32x4 *)&vote[4u * (lane + 64u * i)] = u32x4{0u, 0u, 0u, 0u};
         wave_sync();
         // (the offsets of a segment that leave the tile at the same place -- in a stretch of short runs, all of them --
         // vote together)
         auto cast = [&](uint32_t v, uint32_t times) {
-            if (v >= kScoutTile && v < 2u * kScoutTile && lane < kScoutVoters) {
-                const uint32_t rel = v - kScoutTile, bin = rel & (kScoutBins - 1u);
-                atomicAdd(&vote[bin >> 1], times << ((bin & 1u) * 16u));
-            }
+            const uint32_t rel = v - kScoutTile;
+            if (rel < kScoutTile && lane < kScoutVoters) atomicAdd(&vote[rel >> 1], times << ((rel & 1u) * 16u));
         };
-        uint32_t same = tbl[lane], times = 1u;
-#pragma unroll 4
+        uint32_t same = ent[0] & 0xffffu, times = 1u;
+#pragma unroll
         for (uint32_t i = 1; i < kScoutSeg; ++i) {
-            const uint32_t v = tbl[i * kScoutRow + lane];
+            const uint32_t v = (ent[i >> 1] >> ((i & 1u) * 16u)) & 0xffffu;
             if (v != same) {
                 cast(same, times);
                 same = v, times = 0u;
@@ -256,104 +266,38 @@ __global__ __launch_bounds__(256) void scout_table_kernel(const PageDev *__restr
         }
         cast(same, times);
         wave_sync();
-        // the counter with the most votes (votes << 10 | counter)
-        constexpr uint32_t kMine = kScoutBins / 64u;  // counters per lane
+        // The strongest: every lane finds the two strongest of its 32 counters (those of words lane, lane + 64, ...:
+        // votes << 11 | offset), then the wave takes the strongest of the lanes' first four times over, the lane it
+        // came from moving its second up.  (A lane with three of the four strongest loses one: these are guesses.)
+        uint32_t m1 = 0, m2 = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < kScoutTile / 2u / 64u; ++i) {
+            const uint32_t at = lane + 64u * i;
+            const uint32_t word = vote[at];
+            const uint32_t k0 = ((word & 0xffffu) << 11) | (2u * at), k1 = ((word >> 16) << 11) | (2u * at + 1u);
+            m2 = max(m2, min(m1, k0)), m1 = max(m1, k0);
+            m2 = max(m2, min(m1, k1)), m1 = max(m1, k1);
+        }
         uint32_t top[kScoutKeep];
-        {
-            uint32_t best = 0;
 #pragma unroll
-            for (uint32_t i = 0; i < kMine / 2u; ++i) {
-                const uint32_t at = lane * (kMine / 2u) + i;
-                const uint32_t word = vote[at];
-                best = max(best, ((word & 0xffffu) << 10) | (2u * at));
-                best = max(best, ((word >> 16) << 10) | (2u * at + 1u));
-            }
-            top[0] = __builtin_amdgcn_readlane(wave_inclusive_max(best), 63);
+        for (uint32_t r = 0; r < kScoutKeep; ++r) {
+            top[r] = 0u;
+            // (where headers are dense nearly all chains of the tile leave it together: no need for a second guess)
+            if (r != 0u && (top[0] >> 11) >= kScoutSure) continue;
+            top[r] = __builtin_amdgcn_readlane(wave_inclusive_max(m1), 63);
+            if (m1 == top[r]) m1 = m2, m2 = 0u;
         }
-#pragma unroll
-        for (uint32_t r = 1; r < kScoutKeep; ++r) top[r] = 0u;
-        // ... and the next ones, unless nearly all chains of the tile leave it together (dense headers: no need for a
-        // second guess)
-        if ((top[0] >> 10) < kScoutSure) {
-            uint32_t mine[kMine];
-#pragma unroll
-            for (uint32_t i = 0; i < kMine / 2u; ++i) {
-                const uint32_t at = lane * (kMine / 2u) + i;
-                const uint32_t word = vote[at];
-                mine[2u * i] = ((word & 0xffffu) << 10) | (2u * at);
-                mine[2u * i + 1u] = ((word >> 16) << 10) | (2u * at + 1u);
-            }
-#pragma unroll
-            for (uint32_t r = 1; r < kScoutKeep; ++r) {
-                uint32_t best = 0;
-#pragma unroll
-                for (uint32_t i = 0; i < kMine; ++i) {
-                    mine[i] = mine[i] == top[r - 1u] ? 0u : mine[i];
-                    best = max(best, mine[i]);
-                }
-                top[r] = __builtin_amdgcn_readlane(wave_inclusive_max(best), 63);
-            }
+        // candidates for the entry of the next tile: (offset in that tile) << 16 | votes, two votes at least
+        if (lane < kScoutKeep) {
+            const uint32_t mine = lane == 0u ? top[0] : lane == 1u ? top[1] : lane == 2u ? top[2] : top[3];
+            static_assert(kScoutKeep == 4u, "lanes 0..3 write the candidates");
+            hints[(size_t)g * kScoutKeep + lane] = (mine >> 11) >= 2u ? ((mine & (kScoutTile - 1u)) << 16) | (mine >> 11) : 0u;
         }
-        // the two exits that share a counter (one in the near half of the next tile, one in the far half): how many
-        // of the voters leave at either (near | far << 16)
-        const bool sure = (top[0] >> 10) >= kScoutSure;
-        uint32_t both[kScoutKeep];
-#pragma unroll
-        for (uint32_t r = 0; r < kScoutKeep; ++r) both[r] = 0u;
-        if (lane < kScoutVoters) {
-            if (sure) {
-#pragma unroll 4
-                for (uint32_t i = 0; i < kScoutSeg; ++i) {
-                    const uint32_t rel = (uint32_t)tbl[i * kScoutRow + lane] - kScoutTile;
-                    const uint32_t one = rel < kScoutBins ? 1u : rel < kScoutTile ? 0x10000u : 0u;
-                    both[0] += (rel & (kScoutBins - 1u)) == (top[0] & (kScoutBins - 1u)) ? one : 0u;
-                }
-            } else {
-#pragma unroll 4
-                for (uint32_t i = 0; i < kScoutSeg; ++i) {
-                    const uint32_t rel = (uint32_t)tbl[i * kScoutRow + lane] - kScoutTile;
-                    const uint32_t one = rel < kScoutBins ? 1u : rel < kScoutTile ? 0x10000u : 0u;
-#pragma unroll
-                    for (uint32_t r = 0; r < kScoutKeep; ++r)
-                        both[r] += (rel & (kScoutBins - 1u)) == (top[r] & (kScoutBins - 1u)) ? one : 0u;
-                }
-            }
-        }
-#pragma unroll
-        for (uint32_t r = 0; r < kScoutKeep; ++r)
-            both[r] = (sure && r != 0u) || (top[r] >> 10) == 0u ? 0u : __builtin_amdgcn_readlane(wave_inclusive_sum(both[r]), 63);
-        const uint32_t n_near = both[0] & 0xffffu, n_far = both[0] >> 16;
         if (lane == 0) {
-            const uint32_t near = kScoutTile + (top[0] & (kScoutBins - 1u)), far = near + kScoutBins;
-            t.exit[g] = max(n_near, n_far) >= 2u ? t0 + (n_far > n_near ? far : near) : kScoutNone;
-            t.vals[g] = max(n_near, n_far);  // about as many headers as the page's chain has in this tile (count step)
+            const uint32_t votes0 = top[0] >> 11;
+            t.exit[g] = votes0 >= 2u ? t0 + kScoutTile + (top[0] & (kScoutTile - 1u)) : kScoutNone;
+            t.vals[g] = votes0;  // about as many headers as the page's chain has in this tile (count step)
         }
-        // Candidates for the entry of the next tile: (offset in that tile) << 16 | votes, two votes at least, the
-        // first kScoutKeep of: the winning counter's two exits (the one with more voters first), then the other
-        // counters' (near, far).  Lanes 2 r and 2 r + 1 hold counter r's.
-        {
-            const uint32_t r = lane >> 1, is_far = lane & 1u;
-            const uint32_t top_r = r == 0u ? top[0] : r == 1u ? top[1] : r == 2u ? top[2] : top[3];
-            const uint32_t both_r = r == 0u ? both[0] : r == 1u ? both[1] : r == 2u ? both[2] : both[3];
-            static_assert(kScoutKeep == 4u, "lanes 0..7 hold the candidates");
-            const bool want_far = (is_far != 0u) != (r == 0u && n_far > n_near);
-            const uint32_t rel = (top_r & (kScoutBins - 1u)) + (want_far ? kScoutBins : 0u);
-            const uint32_t count = want_far ? both_r >> 16 : both_r & 0xffffu;
-            const bool valid = lane < 2u * kScoutKeep && count >= 2u;
-            const uint64_t valids = __ballot(valid);
-            const uint32_t rank = __builtin_amdgcn_mbcnt_lo((uint32_t)valids, 0u);  // lanes below 32 only
-            uint32_t *const out = hints + (size_t)g * kScoutKeep;
-            if (valid && rank < kScoutKeep) out[rank] = (rel << 16) | count;
-            if (lane < kScoutKeep && lane >= (uint32_t)__popcll(valids)) out[lane] = 0u;
-        }
-    }
-    // the table as it lies in LDS: kScoutTable * 2 = 4224 bytes = 264 pieces of 16
-    u32x4 *const dst = (u32x4 *)(table + (size_t)g * kScoutTable);
-    const u32x4 *const src = (const u32x4 *)tbl;
-#pragma unroll
-    for (uint32_t i = 0; i < 5; ++i) {
-        const uint32_t at = i * 64u + lane;
-        if (at < kScoutTable * 2u / 16u) dst[at] = src[at];
     }
 }
 
@@ -778,14 +722,15 @@ __device__ __forceinline__ void scout_close_page(const PageDev &pg, const uint32
     }
 }
 
-// One workgroup per page.
-__global__ __launch_bounds__(256) void scout_scan_kernel(const PageDev *__restrict__ pages,
+// One workgroup (of kScoutScanThreads) per page.
+__global__ __launch_bounds__(kScoutScanThreads) void scout_scan_kernel(const PageDev *__restrict__ pages,
                                                          const ScoutPage *__restrict__ sp, uint32_t n_pages,
                                                          uint32_t *__restrict__ tiles, uint32_t n_stiles,
                                                          ScoutFin *__restrict__ fin, Resume *__restrict__ resume,
                                                          uint32_t *__restrict__ tile_page, uint32_t *__restrict__ run_pos,
                                                          int32_t *__restrict__ status, const ParseState *__restrict__ state) {
-    __shared__ uint32_t wave_vals[4], wave_runs[4], first_full, last_reached, any_flags;
+    constexpr uint32_t kWaves = kScoutScanThreads / 64u;
+    __shared__ uint32_t wave_vals[kWaves], wave_runs[kWaves], first_full, last_reached, any_flags;
     const uint32_t page = blockIdx.x;
     if (page >= n_pages) return;
     const PageDev pg = pages[page];
@@ -796,7 +741,7 @@ __global__ __launch_bounds__(256) void scout_scan_kernel(const PageDev *__restri
         return;
     }
     // expand_kernel finds its page through tile_page[tile]
-    for (uint32_t k = tid; k < (n + kTileValues - 1u) / kTileValues; k += 256u) tile_page[pg.tile_number(k)] = page;
+    for (uint32_t k = tid; k < (n + kTileValues - 1u) / kTileValues; k += kScoutScanThreads) tile_page[pg.tile_number(k)] = page;
     const ScoutPage s = sp[page];
     if (s.n_tiles == 0u) {  // decoder.rs:31-37: nothing to iterate
         if (wave == 0u) scout_close_page(pg, page, resume, run_pos, status, 0u, 0u, 0, lane);
@@ -806,7 +751,7 @@ __global__ __launch_bounds__(256) void scout_scan_kernel(const PageDev *__restri
     const ScoutTiles t = scout_tiles(tiles, n_stiles);
     if (tid == 0) first_full = kScoutNone, last_reached = 0u, any_flags = 0u;
     uint32_t carry_vals = 0, carry_runs = 0;
-    for (uint32_t k0 = 0; k0 < s.n_tiles; k0 += 256u) {
+    for (uint32_t k0 = 0; k0 < s.n_tiles; k0 += kScoutScanThreads) {
         __syncthreads();
         const uint32_t k = k0 + tid;
         const bool in = k < s.n_tiles;
@@ -820,7 +765,7 @@ __global__ __launch_bounds__(256) void scout_scan_kernel(const PageDev *__restri
         if (lane == 63u) wave_vals[wave] = iv, wave_runs[wave] = ir;
         __syncthreads();
         uint32_t bv = carry_vals, br = carry_runs;
-        for (uint32_t i = 0; i < 4u; ++i) {
+        for (uint32_t i = 0; i < kWaves; ++i) {
             if (i < wave) bv = min(bv + wave_vals[i], kValueCap), br += wave_runs[i];
         }
         const uint32_t excl_v = min(bv + (uint32_t)__builtin_amdgcn_update_dpp(0u, iv, 0x138, 0xf, 0xf, false), kValueCap);  // wave_shr:1
@@ -834,7 +779,7 @@ __global__ __launch_bounds__(256) void scout_scan_kernel(const PageDev *__restri
             if (incl_v >= n && excl_v < n) atomicMin(&first_full, k);
             if (rf & (kScoutPanic | kScoutBad)) atomicOr(&any_flags, rf & (kScoutPanic | kScoutBad));
         }
-        for (uint32_t i = 0; i < 4u; ++i) carry_vals = min(carry_vals + wave_vals[i], kValueCap), carry_runs += wave_runs[i];
+        for (uint32_t i = 0; i < kWaves; ++i) carry_vals = min(carry_vals + wave_vals[i], kValueCap), carry_runs += wave_runs[i];
     }
     __syncthreads();
     if (tid == 0) {
@@ -994,7 +939,7 @@ extern "C" hipError_t pq2_launch_scout(const void *pages, const void *spages, ui
         else
             hipLaunchKernelGGL(scout_count_kernel<false>, dim3(tile_groups), dim3(256), 0, stream, pg, sp, tiles, tbl, n_stiles, done);
     }
-    hipLaunchKernelGGL(scout_scan_kernel, dim3(n_pages), dim3(256), 0, stream, pg, sp, n_pages, tiles, n_stiles, fin,
+    hipLaunchKernelGGL(scout_scan_kernel, dim3(n_pages), dim3(kScoutScanThreads), 0, stream, pg, sp, n_pages, tiles, n_stiles, fin,
                        (Resume *)resume, tile_page, run_pos, status, done);
     if (n_stiles != 0u)
         hipLaunchKernelGGL(scout_place_kernel, dim3(tile_groups), dim3(256), 0, stream, pg, sp, tiles, tbl, n_stiles, fin,

@@ -126,7 +126,7 @@ __device__ __forceinline__ SegHeader scout_header(const SegBytes &sb, const int 
     const uint32_t ind = two ? ((b0 & 0x7fu) | (b1 << 7)) : b0;
     SegHeader h;
     h.c = two ? 2u : 1u;
-    h.body = (ind & 1u) ? (ind >> 1) * w : rb;
+    h.body = (ind & 1u) ? __umul24(ind >> 1, w) : rb;  // 14 bits by 6: the 24-bit multiply runs at full rate
     h.count = (ind & 1u) ? (ind >> 1) * 8u : (ind >> 1);
     h.longer = two && (b1 & 0x80u) != 0u;
     return h;
@@ -134,6 +134,9 @@ __device__ __forceinline__ SegHeader scout_header(const SegBytes &sb, const int 
 
 // Lane l: for every offset i of segment l of the tile at a-offset t0, where the chain of headers that starts at
 // i leaves the segment -- a tile offset >= 32 (l + 1), or an escape -- into tbl[i * kScoutRow + l].
+// kNearEnd: the stream may end within kScoutEsc bytes of the tile's start (elsewhere a run that lies within that
+// reach, which is asked of it anyway, lies inside the stream, and the two comparisons with `end` are left out).
+template <bool kNearEnd>
 __device__ __forceinline__ void scout_segments(const SegBytes &sb, const uint32_t t0, const uint32_t end, const uint32_t w,
                                                uint16_t *tbl, const uint32_t lane) {
     const uint32_t rb = ceil8(w);
@@ -146,7 +149,8 @@ __device__ __forceinline__ void scout_segments(const SegBytes &sb, const uint32_
         const uint32_t nxt = (uint32_t)i + h.c + h.body;   // the next header, from the segment's start
         const uint32_t far = seg_rel + nxt;                // ... from the tile's start
         // the short path of decode_run: a header of one or two bytes whose run lies inside the stream
-        const bool plain = !h.longer && q < end && h.body <= end - q && far < kScoutEsc;
+        bool plain = !h.longer && far < kScoutEsc;
+        if (kNearEnd) plain = plain && q < end && h.body <= end - q;
         const uint32_t inside = tbl[(nxt & 31u) * kScoutRow + lane];  // where the chain from nxt leaves (if nxt < 32)
         uint32_t v = nxt < kScoutSeg ? inside : far;
         if (!plain) v = kScoutEsc | (seg_rel + (uint32_t)i);
@@ -182,7 +186,11 @@ __global__ __launch_bounds__(256) void scout_table_kernel(const PageDev *__restr
         const uint32_t delta = (uint32_t)(pg.in_addr & 15u);
         const uint32_t end = delta + pg.in_len;
         const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(pg.in_addr - delta, (end + 3u) & ~3u);
-        scout_segments(scout_load_segment(rsrc, t0 + lane * kScoutSeg), t0, end, pg.num_bits, tbl, lane);
+        const SegBytes sb = scout_load_segment(rsrc, t0 + lane * kScoutSeg);
+        if (t0 + kScoutEsc + 8u <= end)
+            scout_segments<false>(sb, t0, end, pg.num_bits, tbl, lane);
+        else
+            scout_segments<true>(sb, t0, end, pg.num_bits, tbl, lane);
     }
     wave_sync();
     // the table as it is now -- where every chain leaves its SEGMENT -- is what the count step walks a tile of many

@@ -463,6 +463,8 @@ __device__ __forceinline__ void expand_block(const __amdgpu_buffer_rsrc_t rsrc, 
             LaneRun run;                   // lane r: run ridx + 1 + r
             run.kind = kRle, run.count = 0, run.info = 0;
             bool direct = false;           // a pass of short runs: see below
+            bool next_known = false;
+            uint32_t next_kind = kRle, next_count = 0, next_info = 0;
             if (!alone) {
                 // lane r <- run ridx + 1 + r: position, header, length; a prefix sum places them
                 uint32_t hp = kEndPos;
@@ -482,8 +484,13 @@ __device__ __forceinline__ void expand_block(const __amdgpu_buffer_rsrc_t rsrc, 
                     ok = ok && run.info + ((t + 7u) >> 3) * w + 8u <= win.hi;
                     value = (run.info - win.lo) * 8u - start * w;
                 }
-                const uint64_t bad = __ballot(!ok);  // lane 63 is never valid
+                const uint64_t bad = __ballot(!ok) | (1ull << 63);  // (the table has no place for lane 63's run)
                 g = (uint32_t)__builtin_ctzll(bad);
+                // run ridx + 1 + g, the first run of the next pass, as far as its lane has decoded it
+                next_known = __builtin_amdgcn_readlane((uint32_t)valid, g) != 0u;
+                next_kind = __builtin_amdgcn_readlane(run.kind, g);
+                next_count = __builtin_amdgcn_readlane(run.count, g);
+                next_info = __builtin_amdgcn_readlane(run.info, g);
                 const uint32_t start_g = __builtin_amdgcn_readlane(start, g);
                 const uint32_t hp_g = __builtin_amdgcn_readlane(hp, g);
                 const bool ends = g < kLaneRuns && hp_g == kEndPos;  // no more runs: zeros follow (mod.rs:95)
@@ -498,8 +505,7 @@ __device__ __forceinline__ void expand_block(const __amdgpu_buffer_rsrc_t rsrc, 
                 if (hi < block_n) {  // run ridx + 1 + g will be the first run of the next pass
                     const uint32_t *const at = &hdrs[ridx + 1u + g];
                     ahead_at = kCoh ? load_coherent(at) : *at;
-                    ahead_hp = kEndPos;
-                    if (lane < kLaneRuns) ahead_hp = kCoh ? load_coherent(at + 1u + lane) : at[1u + lane];
+                    ahead_hp = kCoh ? load_coherent(at + 1u + lane) : at[1u + lane];
                 }
             }
             if (direct) {
@@ -672,15 +678,19 @@ __device__ __forceinline__ void expand_block(const __amdgpu_buffer_rsrc_t rsrc, 
             // ---- next pass (rare: more than 63 runs in the block, or bytes beyond the window) --------------
             if (hi < block_n && !alone) {  // run ridx + 1 + g becomes the first run
                 ridx += 1u + g;
-                const uint32_t at = __builtin_amdgcn_readfirstlane(ahead_at);
-                if (!win.holds(at & ~3u, (at & ~3u) + 24u)) win.fill(rsrc, at, (((block_n - hi) * w) >> 3) + 64u, lane);
-                auto rd = [&](uint32_t a) -> uint32_t { return __builtin_amdgcn_readfirstlane(win.dword(a)); };
-                const RunInfo run = decode_run(rd, at, end, w, n - (block_start + hi));
-                if (run.kind >= kEnd || run.count == 0) {  // cannot happen for a listed run; ends the block safely
-                    kind = kRle, rem = kRemMask, payload = 0, skip = 0;
+                if (next_known && next_count != 0u) {  // its lane has read the header already
+                    kind = next_kind, rem = next_count, skip = 0, payload = next_info;
                 } else {
-                    kind = run.kind, rem = run.count, skip = 0;
-                    payload = run.kind == kRle ? run.value : run.payload;
+                    const uint32_t at = __builtin_amdgcn_readfirstlane(ahead_at);
+                    if (!win.holds(at & ~3u, (at & ~3u) + 24u)) win.fill(rsrc, at, (((block_n - hi) * w) >> 3) + 64u, lane);
+                    auto rd = [&](uint32_t a) -> uint32_t { return __builtin_amdgcn_readfirstlane(win.dword(a)); };
+                    const RunInfo first = decode_run(rd, at, end, w, n - (block_start + hi));
+                    if (first.kind >= kEnd || first.count == 0) {  // cannot happen for a listed run; ends the block safely
+                        kind = kRle, rem = kRemMask, payload = 0, skip = 0;
+                    } else {
+                        kind = first.kind, rem = first.count, skip = 0;
+                        payload = first.kind == kRle ? first.value : first.payload;
+                    }
                 }
             }
         }

@@ -382,13 +382,19 @@ __global__ __launch_bounds__(kScoutResolveThreads) void scout_resolve_kernel(con
         uint32_t *const carried = arrays + 4 * stride;  // ... what arrives in tile k from the candidates of tile k - 1
         uint32_t *const own = arrays + 8 * stride;      // ... what the table step handed on
         static_assert(kScoutKeep == 4u, "candidates are loaded four at a time, and the arrays are laid out for four");
+        if (tid == 0) changed = 0u;
+        __syncthreads();
         for (uint32_t k = tid; k < n; k += kScoutResolveThreads) {
             u32x4 h = {(delta << 16) | 0xffffu, 0u, 0u, 0u};  // the page's first byte: known
             if (k != 0u) h = *(const u32x4 *)(hints + ((size_t)s.tile_base + k - 1u) * kScoutKeep);
             own[k] = h.x, own[stride + k] = h.y, own[2 * stride + k] = h.z, own[3 * stride + k] = h.w;
             best[k] = h.x, best[stride + k] = h.y, best[2 * stride + k] = h.z, best[3 * stride + k] = h.w;
+            if (h.y != 0u) changed = 1u;  // a tile with a second candidate: there is something to decide
         }
-        for (uint32_t pass = 0; pass < kScoutPushes; ++pass) {
+        __syncthreads();
+        // (a page of dense headers hands on one candidate per tile: no pass can change anything)
+        const uint32_t passes = changed != 0u ? kScoutPushes : 0u;
+        for (uint32_t pass = 0; pass < passes; ++pass) {
             __syncthreads();
             if (tid == 0) changed = 0u;
 #pragma unroll 2

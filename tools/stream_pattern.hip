@@ -35,24 +35,30 @@ __global__ __launch_bounds__(kThreads) void stream_kernel(const uint8_t *__restr
     const uint32_t tid = threadIdx.x;
     const uint64_t total_steps = (uint64_t)n_regions * kRegionSteps;
     constexpr uint32_t kPieces = kOutStep / 16u / kThreads;  // 16-byte stores per thread and step
-    for (uint64_t it = 0;; ++it) {
-        uint64_t step;
-        if (kPattern == 0) {
-            step = it * gridDim.x + blockIdx.x;
-        } else {
-            const uint64_t region = (it / kRegionSteps) * gridDim.x + blockIdx.x;
-            // pattern 2: the workgroups do not all stand at the same offset of their regions
-            const uint64_t turn = kPattern == 2 ? (uint64_t)blockIdx.x * 37u : 0u;
-            step = region * kRegionSteps + (it + turn) % kRegionSteps;
-        }
-        if (step >= total_steps) break;
-        const uint8_t *const src = in + step * kInStep;
-        uint8_t *const dst = out + step * kOutStep;
-        // 6 KiB: 384 pieces of 16 bytes
+    auto step_of = [&](uint64_t it) -> uint64_t {
+        if (kPattern == 0) return it * gridDim.x + blockIdx.x;
+        const uint64_t region = (it / kRegionSteps) * gridDim.x + blockIdx.x;
+        // pattern 2: the workgroups do not all stand at the same offset of their regions
+        const uint64_t turn = kPattern == 2 ? (uint64_t)blockIdx.x * 37u : 0u;
+        return region * kRegionSteps + (it + turn) % kRegionSteps;
+    };
+    // 6 KiB: 384 pieces of 16 bytes
+    auto load = [&](uint64_t step) -> u32x4 {
         u32x4 v = {0, 0, 0, 0};
+        if (step >= total_steps) return v;
+        const uint8_t *const src = in + step * kInStep;
 #pragma unroll
         for (uint32_t k = 0; k * kThreads < 384u; ++k)
             if (tid + k * kThreads < 384u) v ^= *(const u32x4 *)(src + 16u * (tid + k * kThreads));
+        return v;
+    };
+    // (the loads of the next step are asked for before the stores of the one in hand)
+    u32x4 v = load(step_of(0));
+    for (uint64_t it = 0;; ++it) {
+        const uint64_t step = step_of(it);
+        if (step >= total_steps) break;
+        const u32x4 next = load(step_of(it + 1));
+        uint8_t *const dst = out + step * kOutStep;
 #pragma unroll
         for (uint32_t k = 0; k < kPieces; ++k) {
             const u32x4 o = {v.x + k, v.y, v.z, v.w};
@@ -61,6 +67,7 @@ __global__ __launch_bounds__(kThreads) void stream_kernel(const uint8_t *__restr
             else
                 *(u32x4 *)(dst + 16u * (tid + kThreads * k)) = o;
         }
+        v = next;
     }
 }
 

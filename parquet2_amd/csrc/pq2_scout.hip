@@ -172,15 +172,24 @@ __global__ __launch_bounds__(256) void scout_table_kernel(const PageDev *__restr
     const ScoutTiles t = scout_tiles(tiles, n_stiles);
     // the page this tile belongs to: the last one whose first tile is not behind g (a page without tiles has the
     // first tile of the page behind it, and comes before it); noted for the steps that follow
-    uint32_t page = 0;
-    for (uint32_t step = 1u << (31u - (uint32_t)__builtin_clz(n_pages)); step != 0u; step >>= 1) {
-        const uint32_t p = page + step;
-        if (p < n_pages && __builtin_amdgcn_readfirstlane(sp[p].tile_base) <= g) page = p;
+    // (up to 128 pages: every lane looks at two, one trip to memory; beyond: a binary search, one trip per step)
+    uint32_t page = 0, page_base = 0;
+    if (n_pages <= 128u) {
+        uint32_t b0 = lane < n_pages ? sp[lane].tile_base : 0xffffffffu;
+        uint32_t b1 = lane + 64u < n_pages ? sp[lane + 64u].tile_base : 0xffffffffu;
+        page = (uint32_t)__popcll(__ballot(b0 <= g)) + (uint32_t)__popcll(__ballot(b1 <= g)) - 1u;  // page 0's is 0
+        page_base = page < 64u ? __builtin_amdgcn_readlane(b0, page) : __builtin_amdgcn_readlane(b1, page - 64u);
+    } else {
+        for (uint32_t step = 1u << (31u - (uint32_t)__builtin_clz(n_pages)); step != 0u; step >>= 1) {
+            const uint32_t p = page + step;
+            if (p < n_pages && __builtin_amdgcn_readfirstlane(sp[p].tile_base) <= g) page = p;
+        }
+        page_base = __builtin_amdgcn_readfirstlane(sp[page].tile_base);
     }
     if (lane == 0) t.page[g] = page;
+    const PageDev pg = pages[page];  // (asked for together with the page's state)
     if (scout_page_done(state, page)) return;
-    const PageDev pg = pages[page];
-    const uint32_t t0 = (g - __builtin_amdgcn_readfirstlane(sp[page].tile_base)) * kScoutTile;
+    const uint32_t t0 = (g - page_base) * kScoutTile;
     uint16_t *const tbl = lds[wave];
     {
         const uint32_t delta = (uint32_t)(pg.in_addr & 15u);
@@ -555,15 +564,21 @@ __global__ __launch_bounds__(256) void scout_count_kernel(const PageDev *__restr
     const uint32_t g = blockIdx.x * 4u + wave;
     if (g >= n_stiles) return;
     const ScoutTiles tl = scout_tiles(tiles, n_stiles);
-    if (scout_page_done(state, __builtin_amdgcn_readfirstlane(tl.page[g]))) return;
-    uint32_t pos = __builtin_amdgcn_readfirstlane(tl.entry[g]);
+    // what is known about the tile, asked for in one go, then what is known about its page
+    uint32_t page_v = tl.page[g], pos_v = tl.entry[g], votes_v = tl.vals[g];
+    pin(page_v), pin(pos_v), pin(votes_v);
+    const uint32_t page = __builtin_amdgcn_readfirstlane(page_v);
+    const PageDev pg = pages[page];
+    uint32_t base_v = sp[page].tile_base;
+    const bool done = scout_page_done(state, page);
+    pin(base_v);
+    if (done) return;
+    uint32_t pos = __builtin_amdgcn_readfirstlane(pos_v);
     if (pos == kScoutNone) {
         if (lane == 0) tl.vals[g] = 0u, tl.runs[g] = 0u;
         return;
     }
-    const uint32_t page = __builtin_amdgcn_readfirstlane(tl.page[g]);
-    const PageDev pg = pages[page];
-    const uint32_t t0 = (g - __builtin_amdgcn_readfirstlane(sp[page].tile_base)) * kScoutTile;
+    const uint32_t t0 = (g - __builtin_amdgcn_readfirstlane(base_v)) * kScoutTile;
     const uint32_t tile_end = t0 + kScoutTile;
     const uint32_t delta = (uint32_t)(pg.in_addr & 15u);
     const uint32_t end = delta + pg.in_len;
@@ -581,7 +596,7 @@ __global__ __launch_bounds__(256) void scout_count_kernel(const PageDev *__restr
     // would leave to the exact decoder (the end of the stream is one) the walk below takes over.
     // (The table step's count of the chains that leave the tile together says how many headers to expect; it sees
     // none in the tile that holds the end of the stream.)
-    if (__builtin_amdgcn_readfirstlane(tl.vals[g]) >= kScoutDense || tile_end >= end) {
+    if (__builtin_amdgcn_readfirstlane(votes_v) >= kScoutDense || tile_end >= end) {
         uint16_t *const tbl = seg_lds[wave];
         const SegBytes sb = scout_load_segment(rsrc, t0 + lane * kScoutSeg);
         {  // the per-segment table, as the table step left it
@@ -819,17 +834,23 @@ __global__ __launch_bounds__(256) void scout_place_kernel(const PageDev *__restr
     const uint32_t g = blockIdx.x * 4u + wave;
     if (g >= n_stiles) return;
     const ScoutTiles t = scout_tiles(tiles, n_stiles);
-    const uint32_t page = __builtin_amdgcn_readfirstlane(t.page[g]);
-    if (scout_page_done(state, page)) return;
-    if (__builtin_amdgcn_readfirstlane(t.entry[g]) == kScoutNone) return;
+    // what is known about the tile, asked for in one go, then what is known about its page
+    uint32_t page_v = t.page[g], entry_v = t.entry[g], vals_v = t.base_vals[g], runs_v = t.runs[g], base_runs_v = t.base_runs[g];
+    pin(page_v), pin(entry_v), pin(vals_v), pin(runs_v), pin(base_runs_v);
+    const uint32_t page = __builtin_amdgcn_readfirstlane(page_v);
     const PageDev pg = pages[page];
+    uint32_t base_v = sp[page].tile_base;
+    const bool done = scout_page_done(state, page);
+    pin(base_v);
+    if (done) return;
+    if (__builtin_amdgcn_readfirstlane(entry_v) == kScoutNone) return;
     const uint32_t n = pg.num_values;
-    uint32_t produced = __builtin_amdgcn_readfirstlane(t.base_vals[g]);
+    uint32_t produced = __builtin_amdgcn_readfirstlane(vals_v);
     if (n == 0u || produced >= n) return;  // the page's last value lies in an earlier tile
-    const uint32_t k = g - __builtin_amdgcn_readfirstlane(sp[page].tile_base);
+    const uint32_t k = g - __builtin_amdgcn_readfirstlane(base_v);
     const uint32_t t0 = k * kScoutTile;
-    const uint32_t listed = __builtin_amdgcn_readfirstlane(t.runs[g]) & kScoutRunsMask;
-    uint32_t n_runs = __builtin_amdgcn_readfirstlane(t.base_runs[g]);
+    const uint32_t listed = __builtin_amdgcn_readfirstlane(runs_v) & kScoutRunsMask;
+    uint32_t n_runs = __builtin_amdgcn_readfirstlane(base_runs_v);
     const uint32_t delta = (uint32_t)(pg.in_addr & 15u);
     const uint32_t end = delta + pg.in_len;
     const uint32_t w = pg.num_bits;

@@ -29,7 +29,9 @@ constexpr uint32_t kOutStep = 16384, kInStep = 6144;        // bytes per workgro
 constexpr uint32_t kRegionSteps = 256;                      // steps per region: 4 MiB written
 constexpr uint64_t kRegionOut = (uint64_t)kOutStep * kRegionSteps, kRegionIn = (uint64_t)kInStep * kRegionSteps;
 
-template <int kPattern, int kThreads, bool kNt = false>
+// kPairs: a thread writes two pieces that lie side by side (32 bytes per lane in two stores) instead of pieces a whole
+// workgroup apart (what 8 values per lane and step would mean for a decoder that stores 16 bytes at a time)
+template <int kPattern, int kThreads, bool kNt = false, bool kPairs = false>
 __global__ __launch_bounds__(kThreads) void stream_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
                                                           uint32_t n_regions) {
     const uint32_t tid = threadIdx.x;
@@ -62,25 +64,26 @@ __global__ __launch_bounds__(kThreads) void stream_kernel(const uint8_t *__restr
 #pragma unroll
         for (uint32_t k = 0; k < kPieces; ++k) {
             const u32x4 o = {v.x + k, v.y, v.z, v.w};
+            const uint32_t piece = kPairs ? 2u * tid + (k & 1u) + 2u * kThreads * (k >> 1) : tid + kThreads * k;
             if (kNt)
-                __builtin_nontemporal_store(o, (u32x4 *)(dst + 16u * (tid + kThreads * k)));
+                __builtin_nontemporal_store(o, (u32x4 *)(dst + 16u * piece));
             else
-                *(u32x4 *)(dst + 16u * (tid + kThreads * k)) = o;
+                *(u32x4 *)(dst + 16u * piece) = o;
         }
         v = next;
     }
 }
 
-template <int kPattern, int kThreads, bool kNt = false>
+template <int kPattern, int kThreads, bool kNt = false, bool kPairs = false>
 static double run(const uint8_t *in, uint8_t *out, uint32_t regions, uint32_t grid, int reps) {
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
-    hipLaunchKernelGGL((stream_kernel<kPattern, kThreads, kNt>), dim3(grid), dim3(kThreads), 0, 0, in, out, regions);
+    hipLaunchKernelGGL((stream_kernel<kPattern, kThreads, kNt, kPairs>), dim3(grid), dim3(kThreads), 0, 0, in, out, regions);
     CHECK(hipDeviceSynchronize());
     CHECK(hipEventRecord(e0, 0));
     for (int r = 0; r < reps; ++r)
-        hipLaunchKernelGGL((stream_kernel<kPattern, kThreads, kNt>), dim3(grid), dim3(kThreads), 0, 0, in, out, regions);
+        hipLaunchKernelGGL((stream_kernel<kPattern, kThreads, kNt, kPairs>), dim3(grid), dim3(kThreads), 0, 0, in, out, regions);
     CHECK(hipEventRecord(e1, 0));
     CHECK(hipEventSynchronize(e1));
     float ms = 0;
@@ -116,6 +119,10 @@ int main(int argc, char **argv) {
         const double a = run<0, 256, true>(in, out, regions, grid, 10), b = run<1, 256, true>(in, out, regions, grid, 10);
         printf("nontemporal stores: round robin %.3f ms (%.3f of 8 TB/s), a region per workgroup %.3f ms (%.3f)\n", a,
                bytes / a * 1e-9 / 8.0, b, bytes / b * 1e-9 / 8.0);
+    }
+    if (threads == 256) {
+        const double b = run<1, 256, false, true>(in, out, regions, grid, 10);
+        printf("two pieces side by side per thread: a region per workgroup %.3f ms (%.3f of 8 TB/s)\n", b, bytes / b * 1e-9 / 8.0);
     }
     // what the two directions give alone: the same grid reading / writing 8 GiB
     {

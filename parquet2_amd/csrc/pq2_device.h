@@ -266,27 +266,36 @@ struct LaneRun {
 template <int W>
 __device__ __forceinline__ LaneRun decode_lane(const uint8_t *lds, uint32_t off, uint32_t hp, uint32_t end) {
     constexpr uint32_t w = (uint32_t)W;
+    constexpr uint32_t rb = (w + 7u) >> 3;
     const uint32_t *src = (const uint32_t *)(lds + (off & ~3u));
     const uint32_t sh = (off & 3u) * 8u;
     const uint32_t d0 = src[0], d1 = src[1], d2 = src[2];
     const uint32_t x0 = __builtin_amdgcn_alignbit(d1, d0, sh);
     const uint32_t x1 = __builtin_amdgcn_alignbit(d2, d1, sh);
-    uint64_t ind;
-    uint32_t c, rest;
-    if ((x0 & 0x80u) == 0) {
-        ind = x0 & 0x7fu;
-        c = 1;
-        rest = __builtin_amdgcn_alignbit(x1, x0, 8);
-    } else if ((x0 & 0x8000u) == 0) {
-        ind = (x0 & 0x7fu) | ((x0 >> 1) & 0x3f80u);
-        c = 2;
-        rest = __builtin_amdgcn_alignbit(x1, x0, 16);
-    } else {  // 3..10 header bytes
+    LaneRun r;
+    if (__builtin_expect((x0 & 0x8080u) != 0x8080u, 1)) {
+        // a header of one or two bytes (nearly all are): 32-bit arithmetic does, (ind >> 1) * w < 2^13 * 32
+        const bool two = (x0 & 0x80u) != 0u;
+        const uint32_t ind = two ? (x0 & 0x7fu) | ((x0 >> 1) & 0x3f80u) : x0 & 0x7fu;
+        const uint32_t rest = two ? __builtin_amdgcn_alignbit(x1, x0, 16) : __builtin_amdgcn_alignbit(x1, x0, 8);
+        const uint32_t p = hp + (two ? 2u : 1u);
+        const uint32_t n = ind >> 1;
+        const uint32_t left = end - p;
+        uint32_t k = n * 8u;
+        if (__builtin_expect((ind & 1u) != 0u && n * w > left, 0))  // decoder.rs:51: only whole values inside the remaining bytes
+            k = (left / w) * 8u + ((left % w) * 8u) / w;
+        r.kind = (ind & 1u) ? kBitpacked : kRle;
+        r.count = (ind & 1u) ? k : n;
+        r.info = (ind & 1u) ? p : (rb < 4 ? (rest & ((1u << ((rb & 3u) * 8u)) - 1u)) : rest);
+        return r;
+    }
+    // 3..10 header bytes
+    uint64_t ind = 0;
+    uint32_t c = 0;
+    {
         const uint32_t d3 = src[3], d4 = src[4];
         const uint32_t x2 = __builtin_amdgcn_alignbit(d3, d2, sh);
         const uint32_t x3 = __builtin_amdgcn_alignbit(d4, d3, sh);
-        ind = 0;
-        c = 0;
         bool done = false;
         for (uint32_t i = 0; i < 10 && !done; ++i) {
             const uint32_t word = i < 4 ? x0 : (i < 8 ? x1 : x2);
@@ -298,26 +307,24 @@ __device__ __forceinline__ LaneRun decode_lane(const uint8_t *lds, uint32_t off,
         // the 4 bytes that follow a header of c = 3..10 bytes
         const uint32_t lo_w = c < 4 ? x0 : (c < 8 ? x1 : x2);
         const uint32_t hi_w = c < 4 ? x1 : (c < 8 ? x2 : x3);
-        rest = __builtin_amdgcn_alignbit(hi_w, lo_w, (c & 3u) * 8u);
-    }
-    LaneRun r;
-    const uint32_t p = hp + c;
-    const uint64_t n = ind >> 1;
-    if (ind & 1u) {
-        const uint32_t left = end - p;
-        uint64_t k;
-        if (n > 0x0fffffffull || n * w > left)  // decoder.rs:51: only whole values inside the remaining bytes
-            k = (uint64_t)(left / w) * 8u + ((left % w) * 8u) / w;
-        else
-            k = n * 8u;
-        r.kind = kBitpacked;
-        r.count = k < 0x7fffffffull ? (uint32_t)k : 0x7fffffffu;
-        r.info = p;
-    } else {
-        constexpr uint32_t rb = (w + 7u) >> 3;
-        r.kind = kRle;
-        r.count = n < 0x7fffffffull ? (uint32_t)n : 0x7fffffffu;
-        r.info = rb < 4 ? (rest & ((1u << ((rb & 3u) * 8u)) - 1u)) : rest;
+        const uint32_t rest = __builtin_amdgcn_alignbit(hi_w, lo_w, (c & 3u) * 8u);
+        const uint32_t p = hp + c;
+        const uint64_t n = ind >> 1;
+        if (ind & 1u) {
+            const uint32_t left = end - p;
+            uint64_t k;
+            if (n > 0x0fffffffull || n * w > left)  // decoder.rs:51: only whole values inside the remaining bytes
+                k = (uint64_t)(left / w) * 8u + ((left % w) * 8u) / w;
+            else
+                k = n * 8u;
+            r.kind = kBitpacked;
+            r.count = k < 0x7fffffffull ? (uint32_t)k : 0x7fffffffu;
+            r.info = p;
+        } else {
+            r.kind = kRle;
+            r.count = n < 0x7fffffffull ? (uint32_t)n : 0x7fffffffu;
+            r.info = rb < 4 ? (rest & ((1u << ((rb & 3u) * 8u)) - 1u)) : rest;
+        }
     }
     return r;
 }

@@ -157,8 +157,13 @@ def cpu_baseline(sample, seconds, what):
 def traffic_from_profiles(workload_key, kernel_name):
     """HBM bytes of `kernel_name` per launch from the PMC passes recorded for exactly this workload under
     profiles/ (FETCH_SIZE / WRITE_SIZE cannot be collected from inside the process): (bytes or None, source)."""
-    for name in ("r2_traffic.json", "r1_traffic.json"):
-        path = os.path.join(ROOT, "profiles", name)
+    import glob
+
+    # (the latest first: r2_step3_traffic.json before r1_traffic.json)
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*traffic.json")), reverse=True):
+        name = os.path.basename(path)
+        if "gather" in name:
+            continue
         try:
             t = json.load(open(path))
             if t["workload"] == workload_key and kernel_name in t:

@@ -596,9 +596,20 @@ __global__ __launch_bounds__(256) void scout_count_kernel(const PageDev *__restr
     // would leave to the exact decoder (the end of the stream is one) the walk below takes over.
     // (The table step's count of the chains that leave the tile together says how many headers to expect; it sees
     // none in the tile that holds the end of the stream.)
+    // the tile's bytes and the 64 behind them, for both ways of walking it
+    uint8_t *const win = lds[wave];
+    {
+        static_assert(kScoutWin == 2u * 1024u + 64u, "the window is loaded in two rounds and four pieces");
+        const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rsrc, t0 + lane * 16u, 0, 0);
+        const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rsrc, t0 + 1024u + lane * 16u, 0, 0);
+        u32x4 c = {0u, 0u, 0u, 0u};
+        if (lane < 4u) c = __builtin_amdgcn_raw_buffer_load_b128(rsrc, t0 + 2048u + lane * 16u, 0, 0);
+        *(u32x4 *)&win[lane * 16u] = a;
+        *(u32x4 *)&win[1024u + lane * 16u] = b;
+        if (lane < 4u) *(u32x4 *)&win[2048u + lane * 16u] = c;
+    }
     if (__builtin_amdgcn_readfirstlane(votes_v) >= kScoutDense || tile_end >= end) {
         uint16_t *const tbl = seg_lds[wave];
-        const SegBytes sb = scout_load_segment(rsrc, t0 + lane * kScoutSeg);
         {  // the per-segment table, as the table step left it
             const u32x4 *const src = (const u32x4 *)(table + ((size_t)n_stiles + g) * kScoutTable);
             u32x4 *const dst = (u32x4 *)tbl;
@@ -627,14 +638,22 @@ __global__ __launch_bounds__(256) void scout_count_kernel(const PageDev *__restr
             }
             x = v;
         }
+        // from header to header through the lane's 32 bytes (all of them headers of one or two bytes whose runs lie
+        // inside the stream: the table step has seen to that up to `stop`), as many steps as the segment with the
+        // most headers has
         uint32_t at = mine, held = 0, sum = 0;  // held: bit i = a run that holds values begins at byte i
-#pragma unroll
-        for (int i = 0; i < (int)kScoutSeg; ++i) {
-            const SegHeader h = scout_header(sb, i, w, rb);
-            const bool hit = at == (uint32_t)i && (uint32_t)i < stop;
-            at = hit ? (uint32_t)i + h.c + h.body : at;
-            held |= (hit && h.count != 0u) ? 1u << i : 0u;
-            sum += hit ? h.count : 0u;  // < 32 * 2^16
+        const uint32_t *const win32 = (const uint32_t *)win;
+        while (__ballot(at < stop) != 0) {
+            if (at < stop) {
+                const uint32_t a = lane * kScoutSeg + at;
+                const uint32_t x0 = __builtin_amdgcn_alignbit(win32[(a >> 2) + 1u], win32[a >> 2], (a & 3u) * 8u);
+                const bool two = (x0 & 0x80u) != 0u;
+                const uint32_t ind = two ? (x0 & 0x7fu) | ((x0 >> 1) & 0x3f80u) : x0 & 0x7fu;
+                const uint32_t count = (ind & 1u) ? (ind >> 1) * 8u : ind >> 1;
+                held |= count != 0u ? 1u << at : 0u;
+                sum += count;  // < 32 * 2^16
+                at += (two ? 2u : 1u) + ((ind & 1u) ? __umul24(ind >> 1, w) : rb);
+            }
         }
         const uint32_t n_held = (uint32_t)__popc(held);
         const uint32_t upto = wave_inclusive_sum(n_held);
@@ -645,19 +664,8 @@ __global__ __launch_bounds__(256) void scout_count_kernel(const PageDev *__restr
         pos = __builtin_amdgcn_readfirstlane(t0 + x);  // behind the tile, or the header that is left to the walk
     }
 
-    uint8_t *const win = lds[wave];
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)win;
-    static_assert(kScoutWin == 2u * 1024u + 64u, "the window is loaded in two rounds and four pieces");
-    if (pos < tile_end) {
-        const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rsrc, t0 + lane * 16u, 0, 0);
-        const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rsrc, t0 + 1024u + lane * 16u, 0, 0);
-        u32x4 c = {0u, 0u, 0u, 0u};
-        if (lane < 4u) c = __builtin_amdgcn_raw_buffer_load_b128(rsrc, t0 + 2048u + lane * 16u, 0, 0);
-        *(u32x4 *)&win[lane * 16u] = a;
-        *(u32x4 *)&win[1024u + lane * 16u] = b;
-        if (lane < 4u) *(u32x4 *)&win[2048u + lane * 16u] = c;
-        wave_sync();
-    }
+    wave_sync();
     auto rd = [&](uint32_t a) -> uint32_t { return __builtin_amdgcn_readfirstlane(*(const uint32_t *)&win[a - t0]); };
 
     while (pos < tile_end && term == 0u) {

@@ -278,3 +278,38 @@ def test_schedule_chosen_by_the_caller(oracle):
         assert ctx.last_schedule() == "scout+expand_kernel"
     finally:
         ctx.close()
+
+
+def test_passes_of_short_runs_and_their_edges(any_schedule, oracle):
+    """expand_kernel writes a pass whose runs all hold 8 values or fewer run by run; one run of 9 values, or a first
+    run of more than 64, sends the pass through the run table instead.  Pages that mix both kinds of pass, with the
+    limits on either side: runs of 8 and of 9 values, bit-packed runs of one and of two groups, a first run of 64 and
+    of 65 values in front of short ones, a stream that ends in the middle of a pass (zeros follow), pages that end
+    inside a short run, widths 1, 7, 16, 17 and 32."""
+    rng = np.random.default_rng(21)
+    pages = []
+    for w in (1, 7, 16, 17, 32):
+        for variant in range(6):
+            parts, total = [], 0
+            if variant == 1:
+                parts.append(rle_run(64, 5 % (1 << w), w)); total += 64
+            if variant == 2:
+                parts.append(rle_run(65, 6 % (1 << w), w)); total += 65
+            for i in range(700):
+                r = rng.random()
+                if r < 0.45:
+                    c = int(rng.integers(1, 9))            # 1..8 values
+                elif r < 0.5 and variant >= 3:
+                    c = 9                                   # one too many for the short way
+                else:
+                    c = 0
+                if c:
+                    parts.append(rle_run(c, int(rng.integers(0, 1 << min(w, 31))), w)); total += c
+                else:
+                    g = 2 if (variant >= 4 and rng.random() < 0.05) else 1
+                    parts.append(packed_run(g, w, rng)); total += 8 * g
+            stream = np.frombuffer(b"".join(parts), dtype=np.uint8)
+            n = {0: total, 1: total, 2: total, 3: total - 3, 4: total + 500, 5: total // 2 + 1}[variant]
+            pages.append((stream, w, n))
+    status = check_batch(any_schedule, oracle, pages, align=1)
+    assert (status == OK).all()

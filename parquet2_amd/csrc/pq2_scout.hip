@@ -341,8 +341,8 @@ __device__ __forceinline__ uint32_t scout_leave(const PageDev &pg, const __amdgp
 }
 
 // One workgroup per page.  Dynamic LDS: kScoutResolveArrays arrays of kScoutLdsTiles + 8 words (six for the rounds,
-// twelve while votes are carried forward); pages with more tiles use `scratch` (six arrays of n_tiles + 8 words from
-// word 6 * (tile_base + 8 * page) on) and do without the carried votes.
+// twelve while votes are carried forward); pages with more tiles use `scratch` (as many arrays of n_tiles + 8 words,
+// from word kScoutResolveArrays * (tile_base + 8 * page) on).
 __global__ __launch_bounds__(kScoutResolveThreads) void scout_resolve_kernel(const PageDev *__restrict__ pages,
                                                             const ScoutPage *__restrict__ sp, uint32_t n_pages,
                                                             const uint16_t *__restrict__ table,
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(kScoutResolveThreads) void scout_resolve_kernel(con
     const uint16_t *const page_table = table + (size_t)s.tile_base * kScoutTable;
 
     const uint32_t stride = (n <= kScoutLdsTiles ? kScoutLdsTiles : n) + 8u;
-    uint32_t *const arrays = n <= kScoutLdsTiles ? lds_words : scratch + 6 * ((size_t)s.tile_base + 8u * page);
+    uint32_t *const arrays = n <= kScoutLdsTiles ? lds_words : scratch + kScoutResolveArrays * ((size_t)s.tile_base + 8u * page);
     uint32_t *const cand = arrays;                 // where tile k is entered, as far as is known
     uint32_t *const leave = arrays + stride;       // where the chain from cand[k] leaves tile k
     uint32_t *const flag = arrays + 2 * stride;    // bit 0: leave[k] is out of date; bit 1: tile k is reached;
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(kScoutResolveThreads) void scout_resolve_kernel(con
     // << 16 | votes; every pass adds to the votes of tile k - 1's own chains those of best[.][k - 1], carried through
     // tile k - 1 by its table, and keeps the kScoutKeep strongest: after d passes the votes of d + 1 tiles count.
     // It ends when no tile's strongest candidate changes.  (In LDS, over arrays that are not in use yet.)
-    const bool carry_votes = kScoutPushes != 0u && n <= kScoutLdsTiles;
+    const bool carry_votes = kScoutPushes != 0u;
     if (carry_votes) {
         uint32_t *const best = arrays;                  // best[i * stride + k]
         uint32_t *const carried = arrays + 4 * stride;  // ... what arrives in tile k from the candidates of tile k - 1
@@ -464,8 +464,8 @@ __global__ __launch_bounds__(kScoutResolveThreads) void scout_resolve_kernel(con
         __syncthreads();
     }
 
-    // first guesses: the page's first byte; elsewhere the candidate with the most votes (for a page too large for
-    // the passes above: what the table step saw most chains of the tile before arrive at), or the tile's first byte
+    // first guesses: the page's first byte; elsewhere the candidate with the most votes (without the passes above:
+    // what the table step saw most chains of the tile before arrive at), or the tile's first byte
     for (uint32_t k = tid; k < n; k += kScoutResolveThreads) {
         uint32_t x = k == 0u ? delta : k * kScoutTile;
         bool guess = k != 0u;
@@ -937,7 +937,7 @@ extern "C" size_t pq2_scout_table_bytes(uint64_t n_stiles) { return 2u * (size_t
 // where, in `words`, the resolve step leaves the number of rounds it took for every page (diagnostics)
 extern "C" size_t pq2_scout_rounds_at(uint64_t n_stiles, uint64_t n_pages) { return (7u * (size_t)n_stiles + 2u * (size_t)n_pages) * 4u; }
 extern "C" size_t pq2_scout_words_bytes(uint64_t n_stiles, uint64_t n_pages) {
-    return (7u * (size_t)n_stiles + 3u * (size_t)n_pages + 6u * ((size_t)n_stiles + 8u * (size_t)n_pages) +
+    return (7u * (size_t)n_stiles + 3u * (size_t)n_pages + pq2::kScoutResolveArrays * ((size_t)n_stiles + 8u * (size_t)n_pages) +
             pq2::kScoutKeep * (size_t)n_stiles + 20u) * 4u;
 }
 
@@ -966,7 +966,8 @@ extern "C" hipError_t pq2_launch_scout(const void *pages, const void *spages, ui
     uint32_t *rounds = (uint32_t *)(fin + n_pages);  // per page: rounds of the resolve step (pq2_scout_rounds_at)
     uint32_t *scratch = rounds + n_pages;
     // kScoutKeep words per stream tile, at a multiple of 16 bytes
-    uint32_t *hints = tiles + ((13u * (size_t)n_stiles + 51u * (size_t)n_pages + 3u) & ~(size_t)3u);
+    uint32_t *hints = tiles + ((7u * (size_t)n_stiles + 3u * (size_t)n_pages +
+                                kScoutResolveArrays * ((size_t)n_stiles + 8u * (size_t)n_pages) + 3u) & ~(size_t)3u);
     uint16_t *tbl = (uint16_t *)table;
     const uint32_t tile_groups = (n_stiles + 3u) / 4u;
     if (n_stiles != 0u) {

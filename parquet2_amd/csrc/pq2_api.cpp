@@ -303,6 +303,30 @@ bool takes_ring(const pq2_ctx *ctx, uint64_t n_pages) {
     return ctx->mode == pq2_ctx::kRing || (ctx->mode == pq2_ctx::kAuto && n_pages >= kScoutMaxPages);
 }
 
+// kAuto, a batch of index or level pages: the scout kernels (true) or ring_kernel?  Below kScoutMaxPages pages always
+// the scout kernels.  From there on ring_kernel, whose time is that of its slowest page (one workgroup a page; with
+// more pages than workgroup slots the pages' walks hide behind each other's expansion) -- unless the batch is small
+// enough for the scout kernels, whose time follows the bytes of the whole batch, to be done before one such page is:
+// about a hundred to three hundred large pages.  Both sides of the comparison are what was measured on an MI355X
+// for pages of long runs (microseconds; the scout kernels: 40 + 2.8 per MB of streams + the values at 3.5 TB/s;
+// ring_kernel: 30 + the largest page at 0.57 per KB of stream or at 9.5 GB/s of values, whichever is more).  Pages of
+// very short runs take ring_kernel far longer than that, which only makes the choice of the scout kernels righter;
+// where such pages come in larger batches the caller has to say so (pq2_ctx_set_schedule).
+bool auto_takes_scout(const pq2_page_desc *descs, uint64_t n_pages) {
+    if (n_pages < kScoutMaxPages) return true;
+    constexpr uint64_t kRingSlots = 1024;  // workgroups of ring_kernel that are resident at a time
+    if (n_pages > kRingSlots) return false;
+    double in_total = 0, out_total = 0, in_max = 0, out_max = 0;
+    for (uint64_t i = 0; i < n_pages; ++i) {
+        const double in = double(descs[i].in_len), out = 4.0 * double(descs[i].num_values);
+        in_total += in, out_total += out;
+        in_max = std::max(in_max, in), out_max = std::max(out_max, out);
+    }
+    const double scout_us = 40.0 + in_total * 2.8e-6 + out_total / 3.5e6;
+    const double ring_us = 30.0 + std::max(in_max * 0.57e-3, out_max / 9.5e3);
+    return scout_us * 1.1 < ring_us;
+}
+
 // Validates the batch, builds the device descriptors in pinned memory, uploads
 // them and enqueues parse + expand on `stream`.
 int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const pq2_page_desc *descs, uint64_t n_pages,
@@ -376,7 +400,8 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
     // few pages: no page's walk has another page's expansion to hide behind, so the walk itself is spread over
     // the GPU (not where the streams' addresses are only known on the device)
     if (fused && !takes_ring(ctx, n_pages)) return fail(ctx, PQ2_DEVICE_ERROR, "internal: fused lookup outside ring_kernel");
-    const bool scout = !front && (ctx->mode == pq2_ctx::kScout || (ctx->mode == pq2_ctx::kAuto && n_pages < kScoutMaxPages));
+    const bool scout = !front && !fused &&
+                       (ctx->mode == pq2_ctx::kScout || (ctx->mode == pq2_ctx::kAuto && auto_takes_scout(descs, n_pages)));
     const bool ring = !scout && (ctx->mode == pq2_ctx::kRing || (ctx->mode == pq2_ctx::kAuto && n_pages >= kFusedMinPages));
     // (kScoutMaxPages >= kFusedMinPages: in kAuto a batch is either walked by the scout kernels or takes ring_kernel)
     const bool per_page = ring || ctx->mode == pq2_ctx::kPerPage;

@@ -313,3 +313,41 @@ def test_passes_of_short_runs_and_their_edges(any_schedule, oracle):
             pages.append((stream, w, n))
     status = check_batch(any_schedule, oracle, pages, align=1)
     assert (status == OK).all()
+
+
+def test_schedule_follows_the_batch(oracle):
+    """The default schedule: the scout kernels below 96 pages; from there on ring_kernel, unless the descriptors say
+    that the scout kernels will be through the whole batch before ring_kernel is through its largest page (a hundred
+    or so large pages); more than 1024 pages always take ring_kernel.  Values as the oracle's either way."""
+    import torch
+
+    from parquet2_amd import Context
+
+    ctx = Context(0)
+    try:
+        big, _ = synth.dict_page(synth.seed_for(2, 7), 1 << 19, 12)
+        small, _ = synth.dict_page(synth.seed_for(2, 8), 3000, 12)
+        for pages, want in (([(big, 12, 1 << 19)] * 100, "scout+expand_kernel"),
+                            ([(small, 12, 3000)] * 100, "ring_kernel"),
+                            ([(big, 12, 1 << 19)] * 20 + [(small, 12, 3000)] * 500, "scout+expand_kernel"),
+                            ([(big, 12, 1 << 19)] * 300, "ring_kernel"),
+                            ([(small, 12, 3000)] * 1100, "ring_kernel"),
+                            ([(small, 12, 3000)] * 95, "scout+expand_kernel")):
+            batch = synth.PageBatch()
+            for stream, w, n in pages:
+                batch.add(stream, w, n)
+            data, descs, out_values = batch.finish()
+            d_in = torch.from_numpy(data).cuda()
+            d_out = torch.full((out_values,), -1, dtype=torch.int32, device="cuda")
+            st = ctx.decode_batch_device(d_in.data_ptr(), d_in.numel(), descs, d_out.data_ptr(), out_values,
+                                         torch.cuda.current_stream().cuda_stream)
+            assert ctx.last_schedule() == want, (len(pages), ctx.last_schedule())
+            assert (st == OK).all()
+            got = d_out.cpu().numpy().view(np.uint32)
+            for k in (0, len(pages) // 2, len(pages) - 1):
+                stream, w, n = pages[k]
+                st_o, exp = oracle.hybrid_rle_decode(stream, w, n)
+                o = int(descs[k]["out_off"])
+                assert st_o == OK and (got[o:o + n] == exp).all(), (len(pages), k)
+    finally:
+        ctx.close()

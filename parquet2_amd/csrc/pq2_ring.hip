@@ -12,12 +12,14 @@ extern "C" int pq2_ring_clocks(unsigned long long *out) {
 
 extern "C" uint32_t pq2_ring_ticket_bytes() { return pq2::kRingCuTickets * 4u; }
 
-// One workgroup per page, the stream staged once through an LDS ring.  `max_bits`: the largest width of a page
-// of the batch (wider pages get the larger ring: two workgroups per compute unit instead of four).
+// One workgroup per page, the stream staged once through an LDS ring of 32 KiB, whatever the width: a ring of
+// 64 KiB for pages wider than 16 bits (so that the ring holds the bytes of the three tiles in hand, up to 48 KiB at
+// width 32) leaves room for two workgroups per compute unit instead of four and is 13-17 % slower at every such
+// width.  `max_bits`: the largest width of a page of the batch.
 extern "C" hipError_t pq2_launch_ring(const void *pages, uint32_t n_pages, int32_t *status, uint32_t *cu_tickets,
                                       uint32_t max_bits, const uint32_t *tile_mask, hipStream_t stream) {
     if (n_pages == 0) return hipSuccess;
-    uint32_t ring_bytes = max_bits > 16u ? 65536u : 32768u;
+    uint32_t ring_bytes = 32768u;
     if (const char *v = getenv("PQ2_RING_BYTES")) {  // tuning knob: 16384, 32768 or 65536
         const uint32_t b = (uint32_t)atoi(v);
         if (b == 16384u || b == 32768u || b == 65536u) ring_bytes = b;

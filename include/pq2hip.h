@@ -91,7 +91,8 @@ int32_t pq2_ctx_enable_profiling(pq2_ctx *ctx, int32_t on);
 const char *pq2_ctx_last_schedule(const pq2_ctx *ctx);
 /* How the batches of this context are scheduled: "auto" (the default: the scout kernels for fewer than 96 pages and
  * for up to 1024 pages that they are expected to get through before ring_kernel is done with its largest page,
- * ring_kernel otherwise), "scout", "ring", "tile" (parse_kernel + expand_kernel in rounds),
+ * parse_kernel + expand_kernel for more than 1024 pages of 8192 values or fewer on average, ring_kernel otherwise),
+ * "scout", "ring", "tile" (parse_kernel + expand_kernel in rounds),
  * "page" (decode_kernel).  Every schedule gives the same values and statuses; which one is fastest depends on how
  * dense the run headers are, which the library cannot see from the descriptors: pages of very short runs (a few
  * values each) are faster through "scout" whatever their number, pages of long runs through "ring" from about a

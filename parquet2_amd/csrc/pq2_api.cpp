@@ -402,7 +402,18 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
     if (fused && !takes_ring(ctx, n_pages)) return fail(ctx, PQ2_DEVICE_ERROR, "internal: fused lookup outside ring_kernel");
     const bool scout = !front && !fused &&
                        (ctx->mode == pq2_ctx::kScout || (ctx->mode == pq2_ctx::kAuto && auto_takes_scout(descs, n_pages)));
-    const bool ring = !scout && (ctx->mode == pq2_ctx::kRing || (ctx->mode == pq2_ctx::kAuto && n_pages >= kFusedMinPages));
+    // (a workgroup per page costs a few microseconds before the page's first value is written: pages of a few thousand
+    // values, in batches that fill the GPU either way, go to parse_kernel + expand_kernel, one wave per page and one
+    // per 4096 values -- 65 536 pages of 4096 values: 0.60 against 0.99 ms, 32 768 of 8192: 0.56 against 0.61,
+    // 16 384 of 16 384: 0.54 against 0.46)
+    bool small_pages = false;
+    if (ctx->mode == pq2_ctx::kAuto && !fused && !scout && n_pages > 1024) {
+        uint64_t values = 0;
+        for (uint64_t i = 0; i < n_pages; ++i) values += descs[i].num_values;
+        small_pages = values <= n_pages * 8192;
+    }
+    const bool ring = !scout && !small_pages &&
+                      (ctx->mode == pq2_ctx::kRing || (ctx->mode == pq2_ctx::kAuto && n_pages >= kFusedMinPages));
     // (kScoutMaxPages >= kFusedMinPages: in kAuto a batch is either walked by the scout kernels or takes ring_kernel)
     const bool per_page = ring || ctx->mode == pq2_ctx::kPerPage;
     // tiles are numbered round-major: all tiles of round 0 of all pages, then round 1, ...

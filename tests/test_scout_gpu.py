@@ -318,7 +318,8 @@ def test_passes_of_short_runs_and_their_edges(any_schedule, oracle):
 def test_schedule_follows_the_batch(oracle):
     """The default schedule: the scout kernels below 96 pages; from there on ring_kernel, unless the descriptors say
     that the scout kernels will be through the whole batch before ring_kernel is through its largest page (a hundred
-    or so large pages); more than 1024 pages always take ring_kernel.  Values as the oracle's either way."""
+    or so large pages); more than 1024 pages take ring_kernel, or, where they hold 8192 values or fewer on average,
+    parse_kernel + expand_kernel.  Values as the oracle's either way."""
     import torch
 
     from parquet2_amd import Context
@@ -327,11 +328,13 @@ def test_schedule_follows_the_batch(oracle):
     try:
         big, _ = synth.dict_page(synth.seed_for(2, 7), 1 << 19, 12)
         small, _ = synth.dict_page(synth.seed_for(2, 8), 3000, 12)
+        medium, _ = synth.dict_page(synth.seed_for(2, 9), 20000, 12)
         for pages, want in (([(big, 12, 1 << 19)] * 100, "scout+expand_kernel"),
                             ([(small, 12, 3000)] * 100, "ring_kernel"),
                             ([(big, 12, 1 << 19)] * 20 + [(small, 12, 3000)] * 500, "scout+expand_kernel"),
                             ([(big, 12, 1 << 19)] * 300, "ring_kernel"),
-                            ([(small, 12, 3000)] * 1100, "ring_kernel"),
+                            ([(small, 12, 3000)] * 1100, "expand_kernel"),  # many pages of a few thousand values
+                            ([(medium, 12, 20000)] * 1100, "ring_kernel"),
                             ([(small, 12, 3000)] * 95, "scout+expand_kernel")):
             batch = synth.PageBatch()
             for stream, w, n in pages:

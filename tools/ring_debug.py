@@ -8,7 +8,10 @@ os.environ.setdefault("PQ2_MODE", "ring")
 from parquet2_amd import PAGE_DESC_DTYPE, Context, synth
 pages_n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 n = 1 << 20
-distinct = [synth.dict_page(synth.seed_for(2, p), n, 12) for p in range(16)]
+kind = sys.argv[3] if len(sys.argv) > 3 else "dict"   # dict (width 12) or def (definition levels, width 1)
+bits = 12 if kind == "dict" else 1
+distinct = [synth.dict_page(synth.seed_for(2, p), n, 12) if kind == "dict" else synth.def_levels_page(synth.seed_for(3, p), n)
+            for p in range(16)]
 stride = (max(len(s) for s, _ in distinct) + 16 + 255) // 256 * 256
 h = np.zeros((16, stride), np.uint8)
 for i, (s, _) in enumerate(distinct): h[i, :len(s)] = s
@@ -17,7 +20,7 @@ d_out = torch.zeros(pages_n * n, dtype=torch.int32, device="cuda")
 descs = np.zeros(pages_n, dtype=PAGE_DESC_DTYPE)
 descs["in_off"] = np.arange(pages_n, dtype=np.uint64) * stride
 descs["in_len"] = [len(distinct[i % 16][0]) for i in range(pages_n)]
-descs["num_bits"] = 12; descs["num_values"] = n; descs["out_off"] = np.arange(pages_n, dtype=np.uint64) * n
+descs["num_bits"] = bits; descs["num_values"] = n; descs["out_off"] = np.arange(pages_n, dtype=np.uint64) * n
 ctx = Context(0)
 calls = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 times = []

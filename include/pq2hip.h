@@ -89,7 +89,8 @@ int32_t pq2_ctx_enable_profiling(pq2_ctx *ctx, int32_t on);
  * "scout+expand_kernel": the same behind the scout kernels, which walk the headers of all pages in parallel over
  * tiles of the streams; "" before the first batch).  For benchmark reports. */
 const char *pq2_ctx_last_schedule(const pq2_ctx *ctx);
-/* How the batches of this context are scheduled: "auto" (the default: the scout kernels for fewer than 96 pages and
+/* How the batches of this context are scheduled: "auto" (the default: the scout kernels for fewer than 96 pages, unless
+ * every stream has at most 1 KiB, and
  * for up to 1024 pages that they are expected to get through before ring_kernel is done with its largest page,
  * parse_kernel + expand_kernel for more than 1024 pages of 8192 values or fewer on average, ring_kernel otherwise),
  * "scout", "ring", "tile" (parse_kernel + expand_kernel in rounds),

@@ -303,8 +303,8 @@ bool takes_ring(const pq2_ctx *ctx, uint64_t n_pages) {
     return ctx->mode == pq2_ctx::kRing || (ctx->mode == pq2_ctx::kAuto && n_pages >= kScoutMaxPages);
 }
 
-// kAuto, a batch of index or level pages: the scout kernels (true) or ring_kernel?  Below kScoutMaxPages pages always
-// the scout kernels.  From there on ring_kernel, whose time is that of its slowest page (one workgroup a page; with
+// kAuto, a batch of index or level pages: the scout kernels (true) or ring_kernel?  Below kScoutMaxPages pages the
+// scout kernels (streams of a few hundred bytes aside, see below).  From there on ring_kernel, whose time is that of its slowest page (one workgroup a page; with
 // more pages than workgroup slots the pages' walks hide behind each other's expansion) -- unless the batch is small
 // enough for the scout kernels, whose time follows the bytes of the whole batch, to be done before one such page is:
 // about a hundred to three hundred large pages.  Both sides of the comparison are what was measured on an MI355X
@@ -313,7 +313,6 @@ bool takes_ring(const pq2_ctx *ctx, uint64_t n_pages) {
 // very short runs take ring_kernel far longer than that, which only makes the choice of the scout kernels righter;
 // where such pages come in larger batches the caller has to say so (pq2_ctx_set_schedule).
 bool auto_takes_scout(const pq2_page_desc *descs, uint64_t n_pages) {
-    if (n_pages < kScoutMaxPages) return true;
     constexpr uint64_t kRingSlots = 1024;  // workgroups of ring_kernel that are resident at a time
     if (n_pages > kRingSlots) return false;
     double in_total = 0, out_total = 0, in_max = 0, out_max = 0;
@@ -321,6 +320,16 @@ bool auto_takes_scout(const pq2_page_desc *descs, uint64_t n_pages) {
         const double in = double(descs[i].in_len), out = 4.0 * double(descs[i].num_values);
         in_total += in, out_total += out;
         in_max = std::max(in_max, in), out_max = std::max(out_max, out);
+    }
+    if (n_pages < kScoutMaxPages) {
+        // ... except where every stream is so short that one wave walks it, whatever it holds (a header every two
+        // bytes, 0.06 us each), before the scout kernels' seven launches are through (70 us): 64 pages of 65 536
+        // definition levels take 55 us in ring_kernel and 76 us the other way, 90 pages of 16 384: 34 and 74
+        constexpr double kShortStream = 1024;
+        if (in_max > kShortStream) return true;
+        const double scout_us = 70.0 + in_total * 2.8e-6 + out_total / 3.5e6;
+        const double ring_us = 30.0 + std::max(in_max * 0.03, out_max / 9.5e3);
+        return scout_us < ring_us;
     }
     const double scout_us = 40.0 + in_total * 2.8e-6 + out_total / 3.5e6;
     const double ring_us = 30.0 + std::max(in_max * 0.57e-3, out_max / 9.5e3);
@@ -413,8 +422,10 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
         small_pages = values <= n_pages * 8192;
     }
     const bool ring = !scout && !small_pages &&
-                      (ctx->mode == pq2_ctx::kRing || (ctx->mode == pq2_ctx::kAuto && n_pages >= kFusedMinPages));
-    // (kScoutMaxPages >= kFusedMinPages: in kAuto a batch is either walked by the scout kernels or takes ring_kernel)
+                      (ctx->mode == pq2_ctx::kRing ||
+                       (ctx->mode == pq2_ctx::kAuto && (n_pages >= kFusedMinPages || (!front && !fused))));
+    // (kScoutMaxPages >= kFusedMinPages: in kAuto a batch whose streams' addresses the host knows is either walked by
+    // the scout kernels or takes ring_kernel)
     const bool per_page = ring || ctx->mode == pq2_ctx::kPerPage;
     // tiles are numbered round-major: all tiles of round 0 of all pages, then round 1, ...
     const bool split = !per_page && !scout && tiles >= ctx->min_rounded_tiles;

@@ -725,9 +725,13 @@ __global__ __launch_bounds__(256) void scout_count_kernel(const PageDev *__restr
         listed += (uint32_t)__popcll(holds);
     }
     if (lane == 0) {
-        // the walk has to leave the tile where the table said it would
+        // The walk has to leave the tile where the table said it would.  "The chain ends here" has two spellings: a
+        // header that lies inside the tile and holds nothing more (decode_run says so: kScoutNone, `term`), and a
+        // position at or behind the last stream byte -- where the stream ends with the tile, the exact decode of a
+        // last header without values (decoder.rs:43-45) says the first and the plain walk over it the second.
         const uint32_t said = tl.exit[g];
-        const bool agrees = term != 0u ? said == kScoutNone : said == pos;
+        const bool said_over = said == kScoutNone || (said != kScoutGaveUp && said >= end);
+        const bool agrees = (term != 0u || pos >= end) ? said_over : said == pos;
         tl.vals[g] = vals;
         tl.runs[g] = listed | (term == kPanic ? kScoutPanic : 0u) | (term != 0u ? kScoutTerm : 0u) | (agrees ? 0u : kScoutBad);
     }

@@ -315,8 +315,48 @@ def test_passes_of_short_runs_and_their_edges(any_schedule, oracle):
     assert (status == OK).all()
 
 
+def test_stream_that_ends_with_a_tile(any_schedule, oracle):
+    """Streams whose last byte is the last byte of a 2 KiB tile of the scout kernels (tiles are cut at multiples of
+    2 KiB from the 16-byte line the stream begins in, so the length depends on the address), ending in: a header
+    with nothing behind it (decoder.rs:43-45: the iterator ends there), of one and of two bytes; an ordinary run; the
+    first byte of a longer header.  Statuses and values as the oracle's."""
+    rng = np.random.default_rng(33)
+    batch = synth.PageBatch(align=1)
+    pages = []
+    for w in (1, 12, 20):
+        rb = (w + 7) // 8
+        for tiles in (1, 2, 3):
+            for tail in (b"\x01", b"\x10", b"\x81\x00", b"", b"\x80"):
+                pad = 1 + len(pages) % 7
+                batch.chunks.append(np.full(pad, 0x02, np.uint8))
+                batch.in_bytes += pad
+                length = 2048 * tiles - (batch.in_bytes & 15)
+                parts, total, size = [], 0, len(tail)
+                while size + 1 + rb <= length:
+                    c = int(rng.integers(1, 64))
+                    parts.append(rle_run(c, int(rng.integers(0, 1 << min(w, 31))), w))
+                    total += c
+                    size += 1 + rb
+                parts.extend([b"\x01"] * (length - size))  # headers of bit-packed runs of no groups: one byte each
+                stream = np.frombuffer(b"".join(parts) + tail, dtype=np.uint8)
+                assert stream.size == length
+                n = total + (100 if tiles == 2 else 0)
+                batch.add(stream, w, n, out_align=1)
+                pages.append((stream, w, n))
+    data, descs, out_values = batch.finish()
+    assert all(((int(d["in_off"]) & 15) + int(d["in_len"])) % 2048 == 0 for d in descs)
+    got, status = any_schedule.decode_batch_host(data, descs, out_values)
+    for k, (stream, w, n) in enumerate(pages):
+        st_o, exp = oracle.hybrid_rle_decode(stream, w, n)
+        assert status[k] == st_o, (k, w, n, status[k], st_o)
+        if st_o == OK:
+            o = int(descs[k]["out_off"])
+            assert (got[o:o + n] == exp).all(), (k, w, n)
+
+
 def test_schedule_follows_the_batch(oracle):
-    """The default schedule: the scout kernels below 96 pages; from there on ring_kernel, unless the descriptors say
+    """The default schedule: the scout kernels below 96 pages (ring_kernel where every stream has at most 1 KiB and
+    no page's values keep one workgroup busy for longer than the scout kernels take); from there on ring_kernel, unless the descriptors say
     that the scout kernels will be through the whole batch before ring_kernel is through its largest page (a hundred
     or so large pages); more than 1024 pages take ring_kernel, or, where they hold 8192 values or fewer on average,
     parse_kernel + expand_kernel.  Values as the oracle's either way."""
@@ -329,13 +369,27 @@ def test_schedule_follows_the_batch(oracle):
         big, _ = synth.dict_page(synth.seed_for(2, 7), 1 << 19, 12)
         small, _ = synth.dict_page(synth.seed_for(2, 8), 3000, 12)
         medium, _ = synth.dict_page(synth.seed_for(2, 9), 20000, 12)
+        levels, _ = synth.def_levels_page(synth.seed_for(3, 1), 16384)  # a stream of a few hundred bytes
+        assert levels.size <= 1024
+        n_long = 1 << 22
+        v, head = n_long << 1, bytearray()
+        while v >= 0x80:
+            head.append((v & 0x7F) | 0x80)
+            v >>= 7
+        head.append(v)
+        long_run = np.frombuffer(bytes(head) + b"\x34\x02", dtype=np.uint8)  # six bytes, 4 Mi values
         for pages, want in (([(big, 12, 1 << 19)] * 100, "scout+expand_kernel"),
                             ([(small, 12, 3000)] * 100, "ring_kernel"),
                             ([(big, 12, 1 << 19)] * 20 + [(small, 12, 3000)] * 500, "scout+expand_kernel"),
                             ([(big, 12, 1 << 19)] * 300, "ring_kernel"),
                             ([(small, 12, 3000)] * 1100, "expand_kernel"),  # many pages of a few thousand values
                             ([(medium, 12, 20000)] * 1100, "ring_kernel"),
-                            ([(small, 12, 3000)] * 95, "scout+expand_kernel")):
+                            ([(small, 12, 3000)] * 95, "scout+expand_kernel"),
+                            # streams that one wave has walked before seven launches are through ...
+                            ([(levels, 1, 16384)] * 90, "ring_kernel"),
+                            ([(levels, 1, 16384)] * 3, "ring_kernel"),
+                            # ... unless a page's values take one workgroup longer than that
+                            ([(long_run, 12, n_long)] * 8, "scout+expand_kernel")):
             batch = synth.PageBatch()
             for stream, w, n in pages:
                 batch.add(stream, w, n)

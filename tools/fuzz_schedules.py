@@ -3,7 +3,8 @@
 runs (short and long, RLE and bit-packed, headers of one to four bytes), cut and padded at random, plus pages of random
 bytes, in batches of random size.  Statuses and values must match bit for bit.
 
-usage: fuzz_schedules.py [batches = 40] [seed = 1]      (needs a GPU; prints one line per schedule)"""
+usage: fuzz_schedules.py [batches = 40] [seed = 1] [edges]      (needs a GPU; prints one line per schedule)
+"edges": half of the longer streams are cut so that they end within a few bytes of a 2 KiB tile boundary."""
 import os
 import sys
 
@@ -68,6 +69,7 @@ def random_page(rng):
 def main():
     batches = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    edges = len(sys.argv) > 3 and sys.argv[3] == "edges"
     oracle = get_oracle()
     ctx = Context(0)
     for schedule in ("scout", "ring", "tile", "page", "auto"):
@@ -80,6 +82,14 @@ def main():
             pages = []
             for _ in range(n_pages):
                 stream, w, n = random_page(rng)
+                if edges and stream.size > 2048 and rng.random() < 0.5:
+                    # cut so that the stream ends at, or a byte or two either side of, a multiple of 2 KiB counted
+                    # from the 16-byte line it begins in (where the scout kernels cut their tiles)
+                    delta = batch.in_bytes & 15
+                    want = int(rng.choice([0, 0, 1, 2, 3, 2045, 2046, 2047]))
+                    size = stream.size - (delta + stream.size - want) % 2048
+                    if size > 0:
+                        stream = stream[:size]
                 batch.add(stream, w, n, out_align=1)
                 pages.append((stream, w, n))
             data, descs, out_values = batch.finish()

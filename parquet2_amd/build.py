@@ -47,8 +47,9 @@ def build_synth(force=False, verbose=False):
     return SYNTH_LIB
 
 
-def build(force=False, verbose=False, extra_flags=(), lib=LIB, obj_dir=OBJ_DIR):
-    """`lib` / `obj_dir` / `extra_flags`: A/B builds (tools/build_variant.sh) next to the product library."""
+def build(force=False, verbose=False, extra_flags=(), lib=LIB, obj_dir=OBJ_DIR, only=None):
+    """`lib` / `obj_dir` / `extra_flags`: A/B builds (tools/build_variant.sh) next to the product library.
+    `only`: the sources an A/B build compiles with its flags; the others are linked as the product build has them."""
     build_synth(force, verbose)
     if not force and lib == LIB and up_to_date():
         return lib
@@ -59,6 +60,8 @@ def build(force=False, verbose=False, extra_flags=(), lib=LIB, obj_dir=OBJ_DIR):
 
     def compile_one(src):
         path = os.path.join(CSRC, src)
+        if only is not None and src not in only:
+            return os.path.join(OBJ_DIR, src + ".o")
         obj = os.path.join(obj_dir, src + ".o")
         if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(path), newest_header):
             return obj
@@ -80,9 +83,10 @@ def build(force=False, verbose=False, extra_flags=(), lib=LIB, obj_dir=OBJ_DIR):
 if __name__ == "__main__":
     flags = [a for a in sys.argv[1:] if a.startswith("-D")]
     name = next((a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--variant=")), None)
-    if name:  # python -m parquet2_amd.build --variant=<name> -DFLAG...: lib/variants/libpq2hip_<name>.so
+    only = next((a.split("=", 1)[1].split(",") for a in sys.argv[1:] if a.startswith("--only=")), None)
+    if name:  # python -m parquet2_amd.build --variant=<name> [--only=a.hip,b.hip] -DFLAG...: lib/variants/libpq2hip_<name>.so
         print(build(force=True, verbose=True, extra_flags=flags,
                     lib=os.path.join(LIB_DIR, "variants", "libpq2hip_%s.so" % name),
-                    obj_dir=os.path.join(LIB_DIR, "obj_" + name)))
+                    obj_dir=os.path.join(LIB_DIR, "obj_" + name), only=only))
     else:
         print(build(force="--force" in sys.argv, verbose=True, extra_flags=flags))

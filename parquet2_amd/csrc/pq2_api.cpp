@@ -46,13 +46,13 @@ hipError_t pq2_launch_bitunpack64(const void *d_packed, uint32_t packed_len, uin
                                   uint64_t *d_out, hipStream_t stream);
 hipError_t pq2_launch_delta(const void *pages, uint32_t n_pages, void *results, hipStream_t stream);
 int32_t pq2_noalloc_setup(int32_t device, uint8_t **out);  // pq2_noalloc.hip
-hipError_t pq2_launch_ring(const void *pages, uint32_t n_pages, int32_t *status, uint32_t *cu_tickets, uint32_t max_bits,
-                           const uint32_t *tile_mask, hipStream_t stream);  // pq2_ring.hip
+hipError_t pq2_launch_ring(const void *pages, uint32_t n_pages, int32_t *status, uint32_t *cu_tickets, uint32_t epoch,
+                           uint32_t max_bits, const uint32_t *tile_mask, hipStream_t stream);  // pq2_ring.hip
 uint32_t pq2_ring_ticket_bytes();
 uint32_t pq2_ring_dict_max_bits();  // pq2_ring_dict.hip
 uint32_t pq2_ring_dict_max_bytes();
 hipError_t pq2_launch_ring_dict(const void *pages, uint32_t n_pages, int32_t *status, uint32_t *cu_tickets,
-                                const uint32_t *tile_mask, const void *dicts, uint32_t value_words, uint32_t max_dict_bytes,
+                                uint32_t epoch, const uint32_t *tile_mask, const void *dicts, uint32_t value_words, uint32_t max_dict_bytes,
                                 hipStream_t stream);
 uint32_t pq2_scout_tile_bytes();  // pq2_scout.hip
 size_t pq2_scout_table_bytes(uint64_t n_stiles);
@@ -171,7 +171,8 @@ struct pq2_ctx {
     hipEvent_t meta_copied = nullptr;  // the previous upload has left h_meta
     bool meta_in_flight = false;
     DevBuf d_meta, d_status, d_resume, d_tile_page, d_run_pos, d_state;
-    DevBuf d_tickets;  // decode_kernel's per-compute-unit counters (zeroed once; only their low bits matter)
+    DevBuf d_tickets;  // per-compute-unit counters: decode_kernel's (zeroed once; only their low bits matter), then ring_kernel's
+    uint32_t ring_epoch = 0;  // ring_kernel launches so far: which half of its counters a launch counts in
     DevBuf d_scout_table, d_scout_words;  // the scout kernels' tables and per-tile words
     uint64_t last_scout_tiles = 0;        // stream tiles of the last batch, if the scout kernels walked it
     bool last_scout = false;
@@ -545,20 +546,21 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
     };
     if (per_page) {
         if (!ctx->d_tickets.ptr) {
-            const size_t ticket_bytes = std::max(pq2_cu_ticket_bytes(), pq2_ring_ticket_bytes());
+            const size_t ticket_bytes = pq2_cu_ticket_bytes() + pq2_ring_ticket_bytes();
             if ((st = reserve(ctx, ctx->d_tickets, ticket_bytes))) return st;
             PQ2_HIP(ctx, hipMemsetAsync(ctx->d_tickets.ptr, 0, ticket_bytes, stream));
         }
         if (fused)  // the walking wave and the expanding waves merge what they report: from 0
             PQ2_HIP(ctx, hipMemsetAsync(d_status, 0, n_pages * sizeof(int32_t), stream));
         if ((st = stamped(true, stream, [&] {
+                 uint32_t *const ring_tickets = static_cast<uint32_t *>(ctx->d_tickets.ptr) + pq2_cu_ticket_bytes() / 4u;
                  if (fused)
-                     return pq2_launch_ring_dict(d_pages, static_cast<uint32_t>(n_pages), d_status,
-                                                 static_cast<uint32_t *>(ctx->d_tickets.ptr), d_tile_mask, fused->d_dicts,
-                                                 fused->value_words, fused->max_dict_bytes, stream);
+                     return pq2_launch_ring_dict(d_pages, static_cast<uint32_t>(n_pages), d_status, ring_tickets,
+                                                 ctx->ring_epoch++, d_tile_mask, fused->d_dicts, fused->value_words,
+                                                 fused->max_dict_bytes, stream);
                  if (ring)
-                     return pq2_launch_ring(d_pages, static_cast<uint32_t>(n_pages), d_status,
-                                            static_cast<uint32_t *>(ctx->d_tickets.ptr), max_bits, d_tile_mask, stream);
+                     return pq2_launch_ring(d_pages, static_cast<uint32_t>(n_pages), d_status, ring_tickets,
+                                            ctx->ring_epoch++, max_bits, d_tile_mask, stream);
                  return pq2_launch_decode(d_pages, static_cast<uint32_t>(n_pages), ctx->d_resume.ptr, d_run_pos, d_status,
                                           ctx->d_state.ptr, static_cast<uint32_t *>(ctx->d_tickets.ptr), max_bits,
                                           d_tile_mask, stream);

@@ -445,9 +445,9 @@ struct FieldWords {
     static constexpr int NY = (4 * W + 31) / 32;
     uint32_t x[NY + 1];
     uint32_t s;
-    __device__ __forceinline__ void pin_all() {
+    __device__ __forceinline__ void pin_all() {  // from the dword read last to the one read first: one wait
 #pragma unroll
-        for (int i = 0; i <= NY; ++i) pin(x[i]);
+        for (int i = NY; i >= 0; --i) pin(x[i]);
     }
     __device__ __forceinline__ u32x4 fields4() const {
         uint32_t y[NY];

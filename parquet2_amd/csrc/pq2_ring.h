@@ -52,6 +52,12 @@ constexpr uint32_t kPassBytes = PQ2_RING_PASS_BYTES;
 #ifndef PQ2_RING_WALK_PRIO
 #define PQ2_RING_WALK_PRIO 2
 #endif
+#ifndef PQ2_RING_PRIO_TURNS
+#define PQ2_RING_PRIO_TURNS 1  // 0: the walking wave above the others, and nothing else (A/B builds)
+#endif
+#ifndef PQ2_RING_FILL_POLICY
+#define PQ2_RING_FILL_POLICY ""  // cache policy bits of the ring fills (" nt": the stream is read once)
+#endif
 constexpr uint32_t kNotYet = 0xfffffffeu;       // header position of a run the walk has not published yet
 constexpr uint32_t kTileFresh = 0xffffffffu;    // "lowest byte needed" of a wave that has not looked at its tile yet
 constexpr uint32_t kNoNeed = 0xffffffc0u;       // ... of a wave that needs no stream byte any more
@@ -88,10 +94,17 @@ struct RingSpan {
 };
 static_assert(RingSpan<2>::kBytes == RingSpan<4>::kBytes, "either chunk index fits the same LDS");
 constexpr uint32_t kRingNoRun = 0xffffffffu;
+// Emission steps whose LDS reads are in flight together: all nine of a span in the kernel for pages of at most 16
+// bits, where the dwords of nine chunks fit the registers of a wave (four waves per SIMD: 128 each); five in the
+// kernel that also takes wider pages (nine there make the compiler keep the kernel's long-lived values in scratch
+// memory, and an expanding wave that waits for a scratch load waits for its stores).
 #ifndef PQ2_RING_STEP_GROUP
-#define PQ2_RING_STEP_GROUP 5
+#define PQ2_RING_STEP_GROUP 9
 #endif
-constexpr uint32_t kRingStepGroup = PQ2_RING_STEP_GROUP;  // emission steps whose LDS reads are in flight together
+#ifndef PQ2_RING_STEP_GROUP_WIDE
+#define PQ2_RING_STEP_GROUP_WIDE 5
+#endif
+constexpr uint32_t kRingNarrowBits = 16;  // widest page of the kernel for narrow pages
 
 struct RingCtl {
     uint32_t covered;    // values covered by the published entries (kAllParsed: the page's entries are complete)
@@ -107,6 +120,16 @@ struct RingCtl {
 };
 constexpr uint32_t kRingAllParsed = 0xffffffffu;
 
+#ifdef PQ2_RING_TRACE  // diagnostic build: when every page's workgroup began and ended (100 MHz clock) and where it ran
+constexpr uint32_t kRingTracePages = 8192;
+static __device__ unsigned long long g_ring_trace[3 * kRingTracePages];  // per page: begin, end, XCC << 8 | compute unit
+#define PQ2_TRACE_END(PAGE)                                                                                       \
+    do {                                                                                                          \
+        if (lane == 0 && (PAGE) < kRingTracePages) atomicMax(&g_ring_trace[3u * (PAGE) + 1u], (unsigned long long)__builtin_amdgcn_s_memrealtime()); \
+    } while (0)
+#else
+#define PQ2_TRACE_END(PAGE) do { } while (0)
+#endif
 #ifdef PQ2_RING_TIMING  // diagnostic build: shader clocks spent per role and wait, summed over all waves
 // 0 walk total, 1 walk waiting for room, 2 walk waiting for fills, 3 walk chase, 4 walk after its last publish,
 // 8 expand total, 9 waiting for a block start, 10 waiting for runs, 11 waiting for bytes
@@ -255,16 +278,16 @@ __device__ __forceinline__ void ring_walk(const PageDev &pg, const uint32_t page
             "s_mov_b32 %[m0_was], m0\n\t"
             "s_mov_b32 m0, %[dst]\n\t"
             "s_nop 0\n\t"
-            "buffer_load_dwordx4 %[off0], %[rsrc], 0 offen lds\n\t"
+            "buffer_load_dwordx4 %[off0], %[rsrc], 0 offen" PQ2_RING_FILL_POLICY " lds\n\t"
             "s_add_u32 m0, m0, 0x400\n\t"
             "s_nop 0\n\t"
-            "buffer_load_dwordx4 %[off1], %[rsrc], 0 offen lds\n\t"
+            "buffer_load_dwordx4 %[off1], %[rsrc], 0 offen" PQ2_RING_FILL_POLICY " lds\n\t"
             "s_add_u32 m0, m0, 0x400\n\t"
             "s_nop 0\n\t"
-            "buffer_load_dwordx4 %[off2], %[rsrc], 0 offen lds\n\t"
+            "buffer_load_dwordx4 %[off2], %[rsrc], 0 offen" PQ2_RING_FILL_POLICY " lds\n\t"
             "s_add_u32 m0, m0, 0x400\n\t"
             "s_nop 0\n\t"
-            "buffer_load_dwordx4 %[off3], %[rsrc], 0 offen lds\n\t"
+            "buffer_load_dwordx4 %[off3], %[rsrc], 0 offen" PQ2_RING_FILL_POLICY " lds\n\t"
             "s_mov_b32 m0, %[m0_was]"
             : [m0_was] "=&s"(m0_was)
             : [dst] "s"(dst), [rsrc] "s"(rsrc_words), [off0] "v"(off0), [off1] "v"(off1), [off2] "v"(off2),
@@ -460,7 +483,9 @@ __device__ __forceinline__ void ring_walk(const PageDev &pg, const uint32_t page
             const uint32_t voff = ring_lds - (pos & ~rmask);  // this turn of the ring, as if it were the whole stream
             // stops at the end of the stream, of the bytes that have landed, and of this turn of the ring (the
             // mirror holds the 8 bytes of a header that begins in the ring's last bytes)
-            const uint32_t chase_limit = __builtin_amdgcn_readfirstlane(min(min(end - 1u, landed_hi - 9u), pos | rmask));
+            // (and, where passes are limited in bytes, behind the first run that reaches that far)
+            const uint32_t chase_limit = __builtin_amdgcn_readfirstlane(
+                min(min(min(end - 1u, landed_hi - 9u), pos | rmask), kPassBytes == 0xffffffffu ? 0xffffffffu : keep + kPassBytes));
             PQ2_COUNT(0, 1);  // entries into the chase loop
             const uint64_t clock_chase = PQ2_CLOCK();
             if constexpr (kWide) {
@@ -793,7 +818,7 @@ __device__ __forceinline__ void ring_fill_span(Sink &sink, const uint32_t value,
     }
 }
 
-template <int W, uint32_t kSpanBlocks, typename Sink>
+template <int W, uint32_t kSpanBlocks, uint32_t kRingStepGroup, typename Sink>
 __device__ __forceinline__ void ring_expand_span(RingExpander &io, uint2 *tbl, void *cidx_lds, const Resume rs,
                                                  const uint32_t end, const uint32_t n, const uint32_t span_start,
                                                  const uint32_t block_n, Sink &sink, const uint32_t lane) {
@@ -996,7 +1021,15 @@ __device__ __forceinline__ void ring_expand_span(RingExpander &io, uint2 *tbl, v
             // ---- phase 2: one chunk per lane and step ---------------------------------------------------
             const uint32_t q_end = (hi + mis + 3u) >> 2;
             const uint32_t q_first = ((lo + mis) >> 2) + lane;
-            bool ragged = false;
+            // A chunk q is stored by these steps if it lies inside the pass, q_lo <= q < q_hi (one unsigned
+            // comparison of q - q_lo), and the run behind the one that holds its first position starts behind its
+            // last one: 2 (p + 3) + 1 < that run's key, with p = 4 q - mis the chunk's first position.
+            const uint32_t q_lo = (lo + mis + 3u) >> 2, q_hi = (hi + mis) >> 2;
+            const uint32_t q_span = q_hi > q_lo ? q_hi - q_lo : 0u;
+            const uint32_t q_rel = q_first - q_lo;
+            const uint32_t key_first = 8u * q_first + 7u - 2u * mis;
+            // the first and the last chunk of a pass that does not begin or end with a chunk: value by value, below
+            const bool ragged = ((lo + mis) & 3u) != 0u || ((hi + mis) & 3u) != 0u;
             constexpr uint32_t kSteps = 4u * kSpanBlocks + 1u;
 #pragma unroll
             for (uint32_t g0 = 0; g0 < kSteps; g0 += kRingStepGroup) {
@@ -1005,8 +1038,10 @@ __device__ __forceinline__ void ring_expand_span(RingExpander &io, uint2 *tbl, v
 #pragma unroll
                 for (uint32_t i = 0; i < kRingStepGroup; ++i)
                     if (g0 + i < kSteps) j[i] = cidx[min(q_first + 64u * (g0 + i), kRingChunkSlots - 1u)];
+                // (the pins go from the value asked for last to the one asked for first: LDS answers in order, so the
+                // first wait is the only one)
 #pragma unroll
-                for (uint32_t i = 0; i < kRingStepGroup; ++i)
+                for (uint32_t i = kRingStepGroup; i-- > 0;)
                     if (g0 + i < kSteps) pin(j[i]);
                 uint2 e[kRingStepGroup];
                 uint32_t nxt[kRingStepGroup];
@@ -1014,8 +1049,8 @@ __device__ __forceinline__ void ring_expand_span(RingExpander &io, uint2 *tbl, v
                 for (uint32_t i = 0; i < kRingStepGroup; ++i)
                     if (g0 + i < kSteps) e[i] = tbl[j[i]], nxt[i] = tbl[j[i] + 1u].x;
 #pragma unroll
-                for (uint32_t i = 0; i < kRingStepGroup; ++i)
-                    if (g0 + i < kSteps) pin(e[i].x), pin(e[i].y), pin(nxt[i]);
+                for (uint32_t i = kRingStepGroup; i-- > 0;)
+                    if (g0 + i < kSteps) pin(nxt[i]), pin(e[i].y), pin(e[i].x);
                 FieldWords<W> x[kRingStepGroup];
 #pragma unroll
                 for (uint32_t i = 0; i < kRingStepGroup; ++i)
@@ -1024,27 +1059,25 @@ __device__ __forceinline__ void ring_expand_span(RingExpander &io, uint2 *tbl, v
                         x[i] = load_fields<W>(ring, (e[i].y + (uint32_t)p * w) & bit_mask);
                     }
 #pragma unroll
-                for (uint32_t i = 0; i < kRingStepGroup; ++i)
+                for (uint32_t i = kRingStepGroup; i-- > 0;)
                     if (g0 + i < kSteps) x[i].pin_all();
 #pragma unroll
                 for (uint32_t i = 0; i < kRingStepGroup; ++i)
                     if (g0 + i < kSteps) {
                         const uint32_t q = q_first + 64u * (g0 + i);
-                        const bool active = q < q_end;
                         const int32_t p = (int32_t)(q * 4u) - (int32_t)mis;
-                        const bool single = active & (((((uint32_t)(p + 3)) << 1) | 1u) < nxt[i]);
-                        const bool full = (p >= (int32_t)lo) & (p + 4 <= (int32_t)hi);
+                        const bool single = key_first + 512u * (g0 + i) < nxt[i];
+                        const bool full = q_rel + 64u * (g0 + i) < q_span;
                         const u32x4 f = x[i].fields4();
                         const bool rle = (e[i].x & 1u) != 0u;
                         const uint32_t r = e[i].y;
                         const u32x4 v = {rle ? r : f.x, rle ? r : f.y, rle ? r : f.z, rle ? r : f.w};
                         if (single & full) sink.put4(v, p);
-                        ragged = ragged | (single & !full);
                     }
             }
             PQ2_CLOCK_ADD(6, clock_p2);
             const uint64_t clock_st = PQ2_CLOCK();
-            if (__builtin_expect(__ballot(ragged) != 0, 0)) {
+            if (__builtin_expect(ragged, 0)) {
 #pragma unroll
                 for (uint32_t side = 0; side < 2u; ++side) {
                     const uint32_t q = side == 0 ? (lo + mis) >> 2 : q_end - 1u;
@@ -1060,15 +1093,25 @@ __device__ __forceinline__ void ring_expand_span(RingExpander &io, uint2 *tbl, v
                         sink.put1((e.x & 1u) ? e.y : f, at);
                 }
             }
-            // the chunks in which a run starts are left to the lane of that run
-            if (key != kRingNoRun) {
-                const uint32_t q = (start + mis) >> 2;
+            // The chunks in which a run starts are left to the lanes of those runs: of the lanes whose runs start in
+            // one chunk the lowest writes it, whole (one 16-byte store where the chunk lies inside the pass: the
+            // steps above left a hole of 16 bytes there, and a hole filled by one store is one write for the memory
+            // side of the cache instead of four).  A run that starts with its chunk, with no other start behind it
+            // in the chunk, has been written by the steps above.
+            const uint32_t q_run = key != kRingNoRun ? (start + mis) >> 2 : 0xffffffffu;
+            const uint32_t q_below = __builtin_amdgcn_update_dpp(0xffffffffu, q_run, 0x138, 0xf, 0xf, false);  // wave_shr:1
+            if (key != kRingNoRun && q_run != q_below) {
+                const uint32_t q = q_run;
                 const int32_t p = (int32_t)(q * 4u) - (int32_t)mis;  // p <= start < p + 4
                 const int32_t first_pos = max(p, (int32_t)lo), past = min(p + 4, (int32_t)hi);
+                const bool whole = p >= (int32_t)lo && p + 4 <= (int32_t)hi;
                 // the usual case: the run before holds everything in front of this run's first value (its table
                 // entry came over from the lane below), and no further run starts inside the chunk
                 const bool simple = (int32_t)(prev_key >> 1) <= first_pos && next_start >= (uint32_t)past;
-                if (simple) {
+                const bool written = (int32_t)start == p && next_start >= (uint32_t)(p + 4);
+                uint32_t v[4];
+                if (written) {
+                } else if (simple) {
                     uint32_t f[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
@@ -1076,12 +1119,12 @@ __device__ __forceinline__ void ring_expand_span(RingExpander &io, uint2 *tbl, v
                         f[k] = field_at<W>(ring, ((pk >= start ? y : prev_y) + pk * w) & bit_mask);
                     }
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) pin(f[k]);
+                    for (int k = 4; k-- > 0;) pin(f[k]);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const bool own = p + k >= (int32_t)start;
                         const uint32_t ek = own ? key : prev_key, ey = own ? y : prev_y;
-                        if (p + k >= first_pos && p + k < past) sink.put1((ek & 1u) ? ey : f[k], p + k);
+                        v[k] = (ek & 1u) ? ey : f[k];
                     }
                 } else {
                     // the chunk's four positions lie in the run that holds its first position and the up to three
@@ -1091,7 +1134,7 @@ __device__ __forceinline__ void ring_expand_span(RingExpander &io, uint2 *tbl, v
 #pragma unroll
                     for (uint32_t i = 0; i < 5u; ++i) t[i] = tbl[min(j0 + i, kRingTableRuns + 1u)];
 #pragma unroll
-                    for (uint32_t i = 0; i < 5u; ++i) pin(t[i].x), pin(t[i].y);
+                    for (uint32_t i = 5u; i-- > 0;) pin(t[i].y), pin(t[i].x);
                     uint2 cur[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
@@ -1109,10 +1152,18 @@ __device__ __forceinline__ void ring_expand_span(RingExpander &io, uint2 *tbl, v
                         f[k] = field_at<W>(ring, (cur[k].y + pk * w) & bit_mask);
                     }
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) pin(f[k]);
+                    for (int k = 4; k-- > 0;) pin(f[k]);
 #pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (p + k >= first_pos && p + k < past) sink.put1((cur[k].x & 1u) ? cur[k].y : f[k], p + k);
+                    for (int k = 0; k < 4; ++k) v[k] = (cur[k].x & 1u) ? cur[k].y : f[k];
+                }
+                if (!written) {
+                    if (whole) {
+                        sink.put4(u32x4{v[0], v[1], v[2], v[3]}, p);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (p + k >= first_pos && p + k < past) sink.put1(v[k], p + k);
+                    }
                 }
             }
             PQ2_CLOCK_ADD(7, clock_st);
@@ -1159,14 +1210,23 @@ constexpr uint32_t kRingCuTickets = 4096;  // entries of the per-compute-unit ti
 
 // Which wave walks: the one on SIMD `ticket % 4` of its compute unit, so that the walks of the workgroups that
 // share a compute unit sit on different SIMDs (see pick_walker in pq2_kernels.hip).  Contains a workgroup barrier.
+//
+// The ticket says how many workgroups of this launch came to the compute unit before this one (`ticket`).  The
+// table has two halves that take turns from launch to launch (`epoch`): a workgroup counts in this launch's half
+// and clears its compute unit's word of the other one, which the next launch counts in.
 __device__ __forceinline__ uint32_t ring_pick_walker(uint32_t *cu_tickets, uint32_t *scratch, const uint32_t wave,
-                                                     const uint32_t lane) {
+                                                     const uint32_t lane, const uint32_t epoch, uint32_t &ticket) {
     const uint32_t hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_REG_HW_ID
     const uint32_t xcc_id = __builtin_amdgcn_s_getreg((3 << 11) | 20);  // HW_REG_XCC_ID
     if (lane == 0) scratch[wave] = (hw_id >> 4) & 3u;                   // SIMD_ID
-    if (threadIdx.x == 0)
-        scratch[7] = atomicAdd(&cu_tickets[(((hw_id >> 8) & 0xffu) | (xcc_id << 8)) & (kRingCuTickets - 1u)], 1u);
+    if (threadIdx.x == 0) {
+        const uint32_t cu = (((hw_id >> 8) & 0xffu) | (xcc_id << 8)) & (kRingCuTickets / 2u - 1u);
+        const uint32_t half = (epoch & 1u) * (kRingCuTickets / 2u);
+        scratch[7] = atomicAdd(&cu_tickets[half + cu], 1u);
+        cu_tickets[(kRingCuTickets / 2u - half) + cu] = 0u;
+    }
     __syncthreads();
+    ticket = __builtin_amdgcn_readfirstlane(scratch[7]);
     const uint32_t target = scratch[7] & 3u;
     uint32_t walker = 0;
     for (uint32_t k = kRingExpanders + 1u; k-- > 0;)
@@ -1195,7 +1255,7 @@ __global__ __launch_bounds__(kRingThreads, PQ2_RING_MIN_WAVES) void ring_kernel(
                                                        int32_t *__restrict__ status, uint32_t *__restrict__ cu_tickets,
                                                        uint32_t ring_bytes, const uint32_t *__restrict__ tile_mask,
                                                        const RingDict *__restrict__ dicts, uint32_t dict_at,
-                                                       uint32_t whole_tile_spans) {
+                                                       uint32_t whole_tile_spans, uint32_t epoch) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1208,6 +1268,13 @@ __global__ __launch_bounds__(kRingThreads, PQ2_RING_MIN_WAVES) void ring_kernel(
         if (threadIdx.x == 0 && kWords == 0) status[page] = 0;
         return;
     }
+#ifdef PQ2_RING_TRACE
+    if (threadIdx.x == 0 && page < kRingTracePages) {
+        g_ring_trace[3u * page] = __builtin_amdgcn_s_memrealtime();
+        g_ring_trace[3u * page + 2u] = ((uint64_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 8) |
+                                       ((__builtin_amdgcn_s_getreg((31 << 11) | 4) >> 8) & 0xffu);
+    }
+#endif
     uint32_t *const dict_lds = (uint32_t *)(lds + dict_at);
     uint32_t dict_len = 0;
     uint64_t value_addr = 0;
@@ -1231,11 +1298,35 @@ __global__ __launch_bounds__(kRingThreads, PQ2_RING_MIN_WAVES) void ring_kernel(
     if (threadIdx.x < kRingExpanders)  // the first tiles are handed out here: wave e holds tile e
         sh.ctl->expander[threadIdx.x] = ((uint64_t)threadIdx.x << 32) | kTileFresh;
     if (threadIdx.x == 0) sh.ctl->next_tile = kRingExpanders;
-    const uint32_t walker = ring_pick_walker(cu_tickets, sh.ctl->pick, wave, lane);  // with a workgroup barrier inside
+    uint32_t ticket;
+    const uint32_t walker = ring_pick_walker(cu_tickets, sh.ctl->pick, wave, lane, epoch, ticket);  // with a workgroup barrier inside
+    // Which workgroup of a compute unit goes first where they compete for issue slots.  The hardware prefers the
+    // older wave, so of the workgroups that come to a compute unit together the first one finishes first, its
+    // successor starts first, is the oldest of the successors and finishes first again: a launch of two pages per
+    // slot ends over a long tail in which the compute units run one, two, three workgroups short.  Priorities by
+    // arrival turn that round: the workgroup that came last goes first, so the slots that took their second
+    // page late are the ones that get through it fast, and the slots of a compute unit end together.
+    // In turns, because a launch goes on: the workgroups that begin together (tickets 0-3, 8-11, ...) are left in
+    // the order the hardware would give them anyway, first come first; their successors (4-7, 12-15, ...), which
+    // begin one after the other as those end, get the reverse.  The walking wave keeps at least the priority it
+    // had before there were turns: a page's walk is its serial part.
+#if PQ2_RING_PRIO_TURNS
+    const uint32_t rank = ticket & 3u;
+    const uint32_t turn = (ticket & 4u) ? rank : 3u - rank;
+    const uint32_t prio_walk = max(turn, (uint32_t)PQ2_RING_WALK_PRIO), prio_expand = turn;
+#else
+    const uint32_t prio_walk = PQ2_RING_WALK_PRIO, prio_expand = 0u;
+#endif
+    {
+        const uint32_t prio = wave == walker ? prio_walk : prio_expand;
+        if (prio == 1u) __builtin_amdgcn_s_setprio(1);
+        if (prio == 2u) __builtin_amdgcn_s_setprio(2);
+        if (prio == 3u) __builtin_amdgcn_s_setprio(3);
+    }
 
     if (wave == walker) {
-        if (PQ2_RING_WALK_PRIO != 0) __builtin_amdgcn_s_setprio(PQ2_RING_WALK_PRIO);
         ring_walk<kWide, kWords != 0>(pg, page, sh, status, lane);
+        PQ2_TRACE_END(page);
         return;
     }
     const uint32_t e = wave - (wave > walker ? 1u : 0u);
@@ -1259,6 +1350,7 @@ __global__ __launch_bounds__(kRingThreads, PQ2_RING_MIN_WAVES) void ring_kernel(
     const uint32_t w = pg.num_bits;
     const uint32_t delta = (uint32_t)(pg.in_addr & 15u);
     const uint32_t end = delta + pg.in_len;
+    constexpr uint32_t kGroup = kWide ? PQ2_RING_STEP_GROUP_WIDE : PQ2_RING_STEP_GROUP;
 
     const uint64_t clock_begin = PQ2_CLOCK();
     for (uint32_t t = e; t < n_tiles;) {
@@ -1291,14 +1383,14 @@ __global__ __launch_bounds__(kRingThreads, PQ2_RING_MIN_WAVES) void ring_kernel(
                 io.raise_need((rs.rem_kind >> 31) == kBitpacked ? rs.payload + (rs.skip >> 3) * w : rs.skip, lane);
 #define PQ2_W(N)                                                                                            \
     case N:                                                                                                 \
-        ring_expand_span<N, kRingSpanBlocks>(io, tbl, cidx, rs, end, n, span_first, span_n, sink, lane);    \
+        ring_expand_span<N, kRingSpanBlocks, kGroup>(io, tbl, cidx, rs, end, n, span_first, span_n, sink, lane);    \
         break;
 #define PQ2_W_LEVELS(N)                                                                                                     \
     case N:                                                                                                                 \
         if (span_blocks == 4u)                                                                                              \
-            ring_expand_span<N, kRingTileBlocks == 4 ? 4 : 2>(io, tbl, cidx, rs, end, n, span_first, span_n, sink, lane);   \
+            ring_expand_span<N, kRingTileBlocks == 4 ? 4 : 2, kGroup>(io, tbl, cidx, rs, end, n, span_first, span_n, sink, lane);   \
         else                                                                                                                \
-            ring_expand_span<N, kRingSpanBlocks>(io, tbl, cidx, rs, end, n, span_first, span_n, sink, lane);                \
+            ring_expand_span<N, kRingSpanBlocks, kGroup>(io, tbl, cidx, rs, end, n, span_first, span_n, sink, lane);                \
         break;
                 if constexpr (kWords == 0) {
                     IndexSink sink = {out + i * span_values};
@@ -1309,11 +1401,26 @@ __global__ __launch_bounds__(kRingThreads, PQ2_RING_MIN_WAVES) void ring_kernel(
 #else
                         PQ2_W_LEVELS(1) PQ2_W_LEVELS(2) PQ2_W(3) PQ2_W(4) PQ2_W(5) PQ2_W(6) PQ2_W(7) PQ2_W(8)
                         PQ2_W(9) PQ2_W(10) PQ2_W(11) PQ2_W(12) PQ2_W(13) PQ2_W(14) PQ2_W(15) PQ2_W(16)
-                        PQ2_W(17) PQ2_W(18) PQ2_W(19) PQ2_W(20) PQ2_W(21) PQ2_W(22) PQ2_W(23) PQ2_W(24)
-                        PQ2_W(25) PQ2_W(26) PQ2_W(27) PQ2_W(28) PQ2_W(29) PQ2_W(30) PQ2_W(31) PQ2_W(32)
 #endif
-                        default:  // width 0 (or beyond 32, whose page has no values): zeros
-                            ring_fill_span(sink, 0u, span_n, lane);
+                        default:
+                            if constexpr (kWide) {
+                                switch (w) {
+#ifndef PQ2_ONLY_W
+                                    PQ2_W(17) PQ2_W(18) PQ2_W(19) PQ2_W(20) PQ2_W(21) PQ2_W(22) PQ2_W(23) PQ2_W(24)
+                                    PQ2_W(25) PQ2_W(26) PQ2_W(27) PQ2_W(28) PQ2_W(29) PQ2_W(30) PQ2_W(31) PQ2_W(32)
+#endif
+                                    default:  // width 0 (or beyond 32, whose page has no values): zeros
+                                        ring_fill_span(sink, 0u, span_n, lane);
+                                        break;
+                                }
+                            } else {
+                                // width 0 (or beyond 32, whose page has no values): zeros; the launcher sends no
+                                // page of 17 to 32 bits to this kernel
+                                if (w > kRingNarrowBits && w <= 32u)
+                                    io.abort_all(lane, 8);
+                                else
+                                    ring_fill_span(sink, 0u, span_n, lane);
+                            }
                             break;
                     }
                 } else {
@@ -1347,6 +1454,7 @@ __global__ __launch_bounds__(kRingThreads, PQ2_RING_MIN_WAVES) void ring_kernel(
     if (kWords != 0 && __ballot(bad_index) != 0 && lane == 0) atomicMax(&status[page], 1);  // PQ2_OUT_OF_SPEC
     PQ2_CLOCK_ADD(8, clock_begin);
     PQ2_CLOCK_FLUSH(8);
+    PQ2_TRACE_END(page);
 }
 
 }  // namespace pq2

@@ -10,14 +10,23 @@ extern "C" int pq2_ring_clocks(unsigned long long *out) {
 }
 #endif
 
+#ifdef PQ2_RING_TRACE
+// copies the per-page trace (3 words per page: begin, end, place) of the first `n_pages` pages to `out`
+extern "C" int pq2_ring_trace(unsigned long long *out, uint32_t n_pages) {
+    if (n_pages > pq2::kRingTracePages) n_pages = pq2::kRingTracePages;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(pq2::g_ring_trace), (size_t)n_pages * 24u) != hipSuccess;
+}
+#endif
+
 extern "C" uint32_t pq2_ring_ticket_bytes() { return pq2::kRingCuTickets * 4u; }
 
 // One workgroup per page, the stream staged once through an LDS ring of 32 KiB, whatever the width: a ring of
 // 64 KiB for pages wider than 16 bits (so that the ring holds the bytes of the three tiles in hand, up to 48 KiB at
 // width 32) leaves room for two workgroups per compute unit instead of four and is 13-17 % slower at every such
 // width.  `max_bits`: the largest width of a page of the batch.
+// `epoch`: a count of the launches that use `cu_tickets` (see ring_pick_walker).
 extern "C" hipError_t pq2_launch_ring(const void *pages, uint32_t n_pages, int32_t *status, uint32_t *cu_tickets,
-                                      uint32_t max_bits, const uint32_t *tile_mask, hipStream_t stream) {
+                                      uint32_t epoch, uint32_t max_bits, const uint32_t *tile_mask, hipStream_t stream) {
     if (n_pages == 0) return hipSuccess;
     uint32_t ring_bytes = 32768u;
     if (const char *v = getenv("PQ2_RING_BYTES")) {  // tuning knob: 16384, 32768 or 65536
@@ -27,7 +36,7 @@ extern "C" hipError_t pq2_launch_ring(const void *pages, uint32_t n_pages, int32
     const uint32_t lds_bytes = pq2::ring_lds_bytes(ring_bytes);
     // a batch of nothing but levels: whole tiles as spans (see kRingWholeTileBits)
     const uint32_t whole_tile_spans = max_bits != 0u && max_bits <= pq2::kRingWholeTileBits ? 1u : 0u;
-    if (max_bits > 16u) {
+    if (max_bits > pq2::kRingNarrowBits) {  // ring_kernel<true, .>: every width, and a header walk that keeps four more bytes per run
         // more than 64 KiB of dynamic LDS has to be asked for (per device; the call is cheap)
         if (lds_bytes > 65536u) {
             hipError_t e = hipFuncSetAttribute((const void *)pq2::ring_kernel<true, 0>,
@@ -36,11 +45,11 @@ extern "C" hipError_t pq2_launch_ring(const void *pages, uint32_t n_pages, int32
         }
         hipLaunchKernelGGL((pq2::ring_kernel<true, 0>), dim3(n_pages), dim3(pq2::kRingThreads), lds_bytes, stream,
                            (const pq2::PageDev *)pages, n_pages, status, cu_tickets, ring_bytes, tile_mask,
-                           (const pq2::RingDict *)nullptr, 0u, whole_tile_spans);
+                           (const pq2::RingDict *)nullptr, 0u, whole_tile_spans, epoch);
     } else {
         hipLaunchKernelGGL((pq2::ring_kernel<false, 0>), dim3(n_pages), dim3(pq2::kRingThreads), lds_bytes, stream,
                            (const pq2::PageDev *)pages, n_pages, status, cu_tickets, ring_bytes, tile_mask,
-                           (const pq2::RingDict *)nullptr, 0u, whole_tile_spans);
+                           (const pq2::RingDict *)nullptr, 0u, whole_tile_spans, epoch);
     }
     return hipGetLastError();
 }

@@ -14,7 +14,7 @@ extern "C" uint32_t pq2_ring_dict_max_bytes() { return 49152u; }
 // dictionary of the batch (at most pq2_ring_dict_max_bytes()); every page is at most pq2_ring_dict_max_bits() wide.
 // The statuses must have been cleared on `stream`.
 extern "C" hipError_t pq2_launch_ring_dict(const void *pages, uint32_t n_pages, int32_t *status, uint32_t *cu_tickets,
-                                           const uint32_t *tile_mask, const void *dicts, uint32_t value_words,
+                                           uint32_t epoch, const uint32_t *tile_mask, const void *dicts, uint32_t value_words,
                                            uint32_t max_dict_bytes, hipStream_t stream) {
     if (n_pages == 0) return hipSuccess;
     const uint32_t dict_bytes = (max_dict_bytes + 15u) & ~15u;
@@ -39,7 +39,7 @@ extern "C" hipError_t pq2_launch_ring_dict(const void *pages, uint32_t n_pages, 
     }                                                                                                                 \
     hipLaunchKernelGGL((pq2::ring_kernel<false, WORDS>), dim3(n_pages), dim3(pq2::kRingThreads), lds_bytes, stream,   \
                        (const pq2::PageDev *)pages, n_pages, status, cu_tickets, ring_bytes, tile_mask,               \
-                       (const pq2::RingDict *)dicts, dict_at, 0u)
+                       (const pq2::RingDict *)dicts, dict_at, 0u, epoch)
     if (value_words == 1u) {
         PQ2_LAUNCH(1);
     } else if (value_words == 2u) {

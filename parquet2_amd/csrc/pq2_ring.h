@@ -52,6 +52,12 @@ constexpr uint32_t kPassBytes = PQ2_RING_PASS_BYTES;
 #ifndef PQ2_RING_WALK_PRIO
 #define PQ2_RING_WALK_PRIO 2
 #endif
+#ifndef PQ2_RING_PRIO_FIRST
+#define PQ2_RING_PRIO_FIRST 0x0123u   // hex digit r: the priority of the r-th workgroup of those that begin together
+#endif
+#ifndef PQ2_RING_PRIO_SECOND
+#define PQ2_RING_PRIO_SECOND 0x3210u  // ... of the r-th of their successors
+#endif
 #ifndef PQ2_RING_PRIO_TURNS
 #define PQ2_RING_PRIO_TURNS 1  // 0: the walking wave above the others, and nothing else (A/B builds)
 #endif
@@ -1312,7 +1318,7 @@ __global__ __launch_bounds__(kRingThreads, PQ2_RING_MIN_WAVES) void ring_kernel(
     // had before there were turns: a page's walk is its serial part.
 #if PQ2_RING_PRIO_TURNS
     const uint32_t rank = ticket & 3u;
-    const uint32_t turn = (ticket & 4u) ? rank : 3u - rank;
+    const uint32_t turn = (((ticket & 4u) ? PQ2_RING_PRIO_SECOND : PQ2_RING_PRIO_FIRST) >> (4u * rank)) & 3u;
     const uint32_t prio_walk = max(turn, (uint32_t)PQ2_RING_WALK_PRIO), prio_expand = turn;
 #else
     const uint32_t prio_walk = PQ2_RING_WALK_PRIO, prio_expand = 0u;

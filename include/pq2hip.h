@@ -69,6 +69,11 @@ typedef struct pq2_page_desc {
 } pq2_page_desc;
 
 /* ---- context ------------------------------------------------------------ */
+/* A context belongs to one GPU and is driven by one thread at a time.  Every
+ * call that takes a context makes that GPU the calling thread's current device
+ * (hipSetDevice) and leaves it so: a caller that works with several GPUs sets
+ * its own device again before its next HIP call.  Streams handed to a call
+ * must belong to the context's GPU. */
 int32_t pq2_ctx_create(int32_t device_id, pq2_ctx **ctx);
 int32_t pq2_ctx_destroy(pq2_ctx *ctx);
 const char *pq2_strerror(int32_t status);
@@ -89,6 +94,10 @@ int32_t pq2_ctx_enable_profiling(pq2_ctx *ctx, int32_t on);
  * "scout+expand_kernel": the same behind the scout kernels, which walk the headers of all pages in parallel over
  * tiles of the streams; "" before the first batch).  For benchmark reports. */
 const char *pq2_ctx_last_schedule(const pq2_ctx *ctx);
+/* Pages handed to pq2_decode_batch_device and pq2_decode_batch_host on this context since it was created (the
+ * pages of a pq2_multi_decode call count for the context that got them).  For tests and reports: which part of a
+ * batch a context was given.  No counterpart in the reference. */
+uint64_t pq2_ctx_pages_total(const pq2_ctx *ctx);
 /* How the batches of this context are scheduled: "auto" (the default: the scout kernels for fewer than 96 pages, unless
  * every stream has at most 1 KiB, and
  * for up to 1024 pages that they are expected to get through before ring_kernel is done with its largest page,
@@ -155,36 +164,32 @@ int32_t pq2_decode_batch_host(pq2_ctx *ctx, const void *h_in, uint64_t in_bytes,
 
 /* No counterpart in the reference.  For callers that cannot allocate: code
  * under HIP graph capture, tight serving loops, harnesses that forbid
- * hipMalloc.  The decode of pq2_decode_batch_device, with everything its
- * kernels need beyond the inputs and outputs (device page descriptors, parse
- * state, the table of block starts, the header-position lists) inside one
- * fixed array of the library's code object, which every GPU the library runs
- * on holds until the process ends (about 34 MiB).  The call allocates nothing
- * and frees nothing; it only enqueues three kernels on `stream` and returns.
+ * hipMalloc.  The decode of pq2_decode_batch_device through the kernel that
+ * takes its large batches (ring_kernel: one workgroup per page, walk and
+ * expansion meet in LDS), with the device memory that kernel needs beyond the
+ * inputs and outputs (its page descriptors, two status arrays, the
+ * per-compute-unit tickets) inside one fixed array of the library's code
+ * object, which every GPU the library runs on holds until the process ends
+ * (about 340 KiB).  The call allocates nothing and frees nothing; it only
+ * enqueues one memset and three kernels on `stream` and returns.
  *
  * Differences from pq2_decode_batch_device:
- *  - no context: `device_id` names the GPU;
+ *  - no context: `device_id` names the GPU, and `stream` must belong to it (the
+ *    calling thread's current device is the same after the call as before);
  *  - `d_descs` and `d_status` are DEVICE arrays of n_pages entries (the caller's
  *    own buffers; d_descs 8-byte aligned): the descriptors are checked on the
  *    device.  A descriptor the host entry point would reject (stream or output
  *    outside the buffers, num_bits > 32 or > max_bits) fails its own page with
  *    PQ2_INVALID_PARAMETER instead of the call; the other pages are decoded;
  *  - `max_bits`: an upper bound of the pages' bit widths (0 = unknown: 32 is
- *    assumed, at the price of larger LDS windows);
- *  - limits: n_pages <= PQ2_NOALLOC_MAX_PAGES and out_values <=
- *    PQ2_NOALLOC_MAX_VALUES, else the call returns PQ2_WOULD_OVER_ALLOCATE and
- *    enqueues nothing; and the header-position lists of the batch, sized as
- *    sum over pages of (min(num_values, in_len / 2) + 128) rounded down to a
- *    multiple of 64, must fit PQ2_NOALLOC_MAX_RUN_ENTRIES: that sum is known
- *    on the device only, and a batch beyond it gets PQ2_WOULD_OVER_ALLOCATE as
- *    the status of every page and decodes nothing;
+ *    assumed; a bound of 16 or less selects the faster kernel for narrow pages);
+ *  - limit: n_pages <= PQ2_NOALLOC_MAX_PAGES, else the call returns
+ *    PQ2_WOULD_OVER_ALLOCATE and enqueues nothing;
  *  - every call on one GPU uses that GPU's one array: calls on one stream
  *    follow each other safely, calls that overlap on one GPU (two streams, two
- *    threads) race.  Nothing in the array has to be cleared between calls.
+ *    threads) race.  The call clears what has to start at zero itself.
  * The statuses are complete when the work on `stream` is. */
 #define PQ2_NOALLOC_MAX_PAGES 4096u
-#define PQ2_NOALLOC_MAX_VALUES (1ull << 26)
-#define PQ2_NOALLOC_MAX_RUN_ENTRIES (8ull << 20)
 int32_t pq2_decode_batch_device_noalloc(int32_t device_id, const void *d_in, uint64_t in_bytes,
                                         const pq2_page_desc *d_descs, uint64_t n_pages, uint32_t max_bits,
                                         uint32_t *d_out, uint64_t out_values, int32_t *d_status, void *stream);
@@ -208,8 +213,11 @@ typedef struct pq2_dict_ref {
  * OptionalDictionary (src/deserialize/native.rs:28-69; the consumer loop
  * `dict.indexes.map(|x| dict.dict.value(x))`, tests/it/read/primitive.rs:99-108).
  * `value_size` is 4 (i32, f32), 8 (i64, f64) or 12 (int96); page i's values go to
- * d_out + descs[i].out_off * value_size (d_out 8-byte aligned).  The indices
- * pass through a buffer the context owns.  An index that is not below
+ * d_out + descs[i].out_off * value_size (d_out 8-byte aligned).  Where the
+ * lookup happens inside the decode kernel (batches that take ring_kernel, pages
+ * of at most 12 bits, dictionaries of at most 48 KiB) the indices never exist in
+ * device memory; otherwise they pass through a buffer the context owns.  An
+ * index that is not below
  * dict_len is Error::OutOfSpec in the reference
  * (tests/it/read/dictionary/primitive.rs:20-27): the page gets status
  * PQ2_OUT_OF_SPEC (unless the index stream itself already failed) and the
@@ -419,7 +427,8 @@ int32_t pq2_partition_pages(const pq2_page_desc *descs, uint64_t n_pages, uint32
  * must be laid out in page order (the spans of the ranges must not
  * interleave); the values between two pages of one range are unspecified
  * after the call.  `status` receives one status per page.  Two contexts on
- * the same device are allowed (they share the GPU). */
+ * the same device are allowed (they share the GPU); the same context twice is
+ * not (PQ2_INVALID_PARAMETER: a context is driven by one thread at a time). */
 int32_t pq2_multi_decode(pq2_ctx *const *ctxs, uint32_t n_ctx, const void *h_in, uint64_t in_bytes,
                          const pq2_page_desc *descs, uint64_t n_pages, uint32_t *h_out, uint64_t out_values,
                          int32_t *status);

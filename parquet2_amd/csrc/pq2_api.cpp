@@ -173,6 +173,7 @@ struct pq2_ctx {
     DevBuf d_meta, d_status, d_resume, d_tile_page, d_run_pos, d_state;
     DevBuf d_tickets;  // per-compute-unit counters: decode_kernel's (zeroed once; only their low bits matter), then ring_kernel's
     uint32_t ring_epoch = 0;  // ring_kernel launches so far: which half of its counters a launch counts in
+    uint64_t pages_total = 0;  // pages handed to pq2_decode_batch_device / _host on this context so far
     DevBuf d_scout_table, d_scout_words;  // the scout kernels' tables and per-tile words
     uint64_t last_scout_tiles = 0;        // stream tiles of the last batch, if the scout kernels walked it
     bool last_scout = false;
@@ -724,6 +725,8 @@ const char *pq2_last_error(const pq2_ctx *ctx) { return ctx ? ctx->last_error.c_
 
 const char *pq2_ctx_last_schedule(const pq2_ctx *ctx) { return ctx ? ctx->last_schedule : ""; }
 
+uint64_t pq2_ctx_pages_total(const pq2_ctx *ctx) { return ctx ? ctx->pages_total : 0; }
+
 int32_t pq2_ctx_scout_rounds(pq2_ctx *ctx, uint32_t *rounds, uint64_t n_pages) {
     if (!ctx || (!rounds && n_pages)) return PQ2_INVALID_PARAMETER;
     if (!ctx->last_scout || n_pages != ctx->last_n_pages)
@@ -773,6 +776,7 @@ int32_t pq2_decode_batch_device(pq2_ctx *ctx, const void *d_in, uint64_t in_byte
                                 void *stream) {
     if (!ctx) return PQ2_INVALID_PARAMETER;
     PQ2_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->pages_total += n_pages;
     int32_t st = enqueue_batch(ctx, d_in, in_bytes, descs, n_pages, d_out, out_values, static_cast<hipStream_t>(stream));
     if (st != PQ2_OK) return st;
     if (status) return fetch_status(ctx, status, n_pages);
@@ -1240,6 +1244,7 @@ int32_t pq2_decode_batch_host(pq2_ctx *ctx, const void *h_in, uint64_t in_bytes,
                               uint64_t n_pages, uint32_t *h_out, uint64_t out_values, int32_t *status) {
     if (!ctx) return PQ2_INVALID_PARAMETER;
     PQ2_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->pages_total += n_pages;
     int32_t st;
     uint64_t total_values = 0;
     for (uint64_t i = 0; i < n_pages; ++i) total_values += descs ? descs[i].num_values : 0;
@@ -1535,6 +1540,10 @@ int32_t pq2_multi_decode(pq2_ctx *const *ctxs, uint32_t n_ctx, const void *h_in,
     if (!ctxs || n_ctx == 0 || (n_pages && (!descs || !status))) return PQ2_INVALID_PARAMETER;
     for (uint32_t r = 0; r < n_ctx; ++r)
         if (!ctxs[r]) return PQ2_INVALID_PARAMETER;
+    // a context is driven by one thread at a time: the same context twice would be driven by two
+    for (uint32_t a = 0; a < n_ctx; ++a)
+        for (uint32_t b = a + 1; b < n_ctx; ++b)
+            if (ctxs[a] == ctxs[b]) return fail(ctxs[0], PQ2_INVALID_PARAMETER, "the same context is listed twice");
     for (uint64_t i = 0; i < n_pages; ++i) {
         const pq2_page_desc &d = descs[i];
         if (d.in_off > in_bytes || d.in_len > in_bytes - d.in_off)
@@ -1579,9 +1588,18 @@ int32_t pq2_multi_decode(pq2_ctx *const *ctxs, uint32_t n_ctx, const void *h_in,
                                           mine.data(), mine.size(), h_out + s.out_lo, s.out_hi - s.out_lo,
                                           status + first);
     };
+    // (a thread that cannot be started must not take the process down through the C boundary: its part is done by
+    // this thread instead)
     std::vector<std::thread> threads;
-    for (uint32_t r = 1; r < n_ctx; ++r) threads.emplace_back(work, r);
-    work(0);
+    std::vector<uint32_t> inline_parts{0};
+    for (uint32_t r = 1; r < n_ctx; ++r) {
+        try {
+            threads.emplace_back(work, r);
+        } catch (const std::exception &) {
+            inline_parts.push_back(r);
+        }
+    }
+    for (uint32_t r : inline_parts) work(r);
     for (std::thread &t : threads) t.join();
     for (uint32_t r = 0; r < n_ctx; ++r)
         if (result[r] != PQ2_OK) return result[r];

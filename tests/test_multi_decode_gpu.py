@@ -84,3 +84,23 @@ def test_interleaved_outputs_are_refused(contexts):
     if n and (partition_pages(descs, 2) == b).all():
         with pytest.raises(InvalidParameter):
             multi_decode(contexts[:2], data, descs, out_values)
+
+
+def test_the_same_context_twice_is_refused(contexts):
+    (data, descs, out_values), _ = mixed_batch(12, 13)
+    with pytest.raises(InvalidParameter):
+        multi_decode([contexts[0], contexts[1], contexts[0]], data, descs, out_values)
+
+
+def test_every_context_decodes_its_part_of_the_partition(contexts):
+    """The page ranges the contexts get are pq2_partition_pages's."""
+    from parquet2_amd._lib import lib
+
+    (data, descs, out_values), _ = mixed_batch(150, 17, True)
+    k = min(3, len(contexts))
+    bounds = partition_pages(descs, k)
+    before = [lib().pq2_ctx_pages_total(c._h) for c in contexts[:k]]
+    multi_decode(contexts[:k], data, descs, out_values)
+    after = [lib().pq2_ctx_pages_total(c._h) for c in contexts[:k]]
+    assert [a - b for a, b in zip(after, before)] == [int(bounds[r + 1] - bounds[r]) for r in range(k)]
+    assert sum(a - b for a, b in zip(after, before)) == len(descs)

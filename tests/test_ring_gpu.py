@@ -158,3 +158,49 @@ def test_many_ragged_pages(ctx, oracle):
         stream = bytes(synth.encode_hybrid(vals, w))
         pages.append((stream, w, n + (int(rng.integers(0, 900)) if p % 5 == 0 else 0)))
     check(ctx, oracle, pages)
+
+
+@pytest.mark.parametrize("schedule", ["ring", "auto"])
+def test_mixed_batch_of_index_and_level_pages(oracle, schedule):
+    """BASELINE configs[4]'s page mix on one GPU: 160 pages of 2^20 values, three in four dictionary-index pages of
+    width 12, one in four definition-level pages of width 1, each replica at its own address.  Every page against
+    the generator's values; one page of each distinct stream against the oracle.  (ring_kernel takes level pages
+    whole tiles at a time only in batches of nothing but level pages: this batch is the other case.)"""
+    import torch
+
+    from parquet2_amd import PAGE_DESC_DTYPE, Context
+
+    n = 1 << 20
+    n_pages, distinct = 160, 4
+    idx = [synth.dict_page(synth.seed_for(2, p), n, 12) for p in range(distinct)]
+    lev = [synth.def_levels_page(synth.seed_for(3, p), n) for p in range(distinct)]
+    for (s, v), w in [(p, 12) for p in idx] + [(p, 1) for p in lev]:
+        st, want = oracle.hybrid_rle_decode(bytes(s), w, n)
+        assert st == OK and np.array_equal(want, v)  # the generator's values are the oracle's
+    stride = (max(len(s) for s, _ in idx + lev) + 16 + 255) // 256 * 256
+    h = np.zeros((2 * distinct, stride), np.uint8)
+    for i, (s, _) in enumerate(idx + lev):
+        h[i, :len(s)] = s
+    which = np.array([(p // 4) % distinct + (distinct if p % 4 == 3 else 0) for p in range(n_pages)])
+    d_in = torch.from_numpy(h).cuda()[torch.from_numpy(which).cuda()].contiguous()
+    d_out = torch.full((n_pages * n,), 0x5A5A5A5A, dtype=torch.int32, device="cuda")
+    descs = np.zeros(n_pages, dtype=PAGE_DESC_DTYPE)
+    descs["in_off"] = np.arange(n_pages, dtype=np.uint64) * stride
+    descs["in_len"] = [len((idx + lev)[k][0]) for k in which]
+    descs["num_bits"] = [12 if k < distinct else 1 for k in which]
+    descs["num_values"] = n
+    descs["out_off"] = np.arange(n_pages, dtype=np.uint64) * n
+    ctx = Context(0)
+    try:
+        ctx.set_schedule(schedule)
+        st = ctx.decode_batch_device(d_in.data_ptr(), d_in.numel(), descs, d_out.data_ptr(), n_pages * n, 0)
+        torch.cuda.synchronize()
+        assert st.tolist() == [OK] * n_pages
+        if schedule == "ring":
+            assert ctx.last_schedule() == "ring_kernel"
+        expect = [torch.from_numpy(v.astype(np.uint32).view(np.int32)).cuda() for _, v in idx + lev]
+        got = d_out.view(n_pages, n)
+        for p in range(n_pages):
+            assert torch.equal(got[p], expect[which[p]]), "page %d (%s)" % (p, "levels" if which[p] >= distinct else "indices")
+    finally:
+        ctx.close()

@@ -66,6 +66,46 @@ def random_page(rng):
     return stream, w, min(n, 1 << 22)
 
 
+def fuzz(ctx, oracle, schedule, batches, seed, edges=False, max_pages=200):
+    """`batches` random batches through `schedule` on `ctx`; returns (pages, values, pages with a status other than
+    ok); raises AssertionError at the first page that differs from the oracle."""
+    ctx.set_schedule(schedule)
+    rng = np.random.default_rng(seed)
+    pages_done = values_done = not_ok = 0
+    for b in range(batches):
+        n_pages = int(rng.integers(1, max_pages))
+        batch = synth.PageBatch(align=1)
+        pages = []
+        for _ in range(n_pages):
+            stream, w, n = random_page(rng)
+            if edges and stream.size > 2048 and rng.random() < 0.5:
+                # cut so that the stream ends at, or a byte or two either side of, a multiple of 2 KiB counted
+                # from the 16-byte line it begins in (where the scout kernels cut their tiles)
+                delta = batch.in_bytes & 15
+                want = int(rng.choice([0, 0, 1, 2, 3, 2045, 2046, 2047]))
+                size = stream.size - (delta + stream.size - want) % 2048
+                if size > 0:
+                    stream = stream[:size]
+            batch.add(stream, w, n, out_align=1)
+            pages.append((stream, w, n))
+        data, descs, out_values = batch.finish()
+        got, status = ctx.decode_batch_host(data, descs, out_values)
+        for k, (stream, w, n) in enumerate(pages):
+            st_o, exp = oracle.hybrid_rle_decode(stream, w, n)
+            assert status[k] == st_o, "%s: batch %d page %d: status %d, oracle %d (w=%d n=%d len=%d)" % (
+                schedule, b, k, status[k], st_o, w, n, stream.size)
+            if st_o == OK:
+                o = int(descs[k]["out_off"])
+                bad = np.nonzero(got[o:o + n] != exp)[0]
+                assert not bad.size, "%s: batch %d page %d (w=%d n=%d len=%d): first mismatch at %d: %d, oracle %d" % (
+                    schedule, b, k, w, n, stream.size, bad[0], got[o + bad[0]], exp[bad[0]])
+            else:
+                not_ok += 1
+            values_done += n
+        pages_done += n_pages
+    return pages_done, values_done, not_ok
+
+
 def main():
     batches = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -73,42 +113,10 @@ def main():
     oracle = get_oracle()
     ctx = Context(0)
     for schedule in ("scout", "ring", "tile", "page", "auto"):
-        ctx.set_schedule(schedule)
-        rng = np.random.default_rng(seed)
-        pages_done = values_done = not_ok = 0
-        for b in range(batches):
-            n_pages = int(rng.integers(1, 200))
-            batch = synth.PageBatch(align=1)
-            pages = []
-            for _ in range(n_pages):
-                stream, w, n = random_page(rng)
-                if edges and stream.size > 2048 and rng.random() < 0.5:
-                    # cut so that the stream ends at, or a byte or two either side of, a multiple of 2 KiB counted
-                    # from the 16-byte line it begins in (where the scout kernels cut their tiles)
-                    delta = batch.in_bytes & 15
-                    want = int(rng.choice([0, 0, 1, 2, 3, 2045, 2046, 2047]))
-                    size = stream.size - (delta + stream.size - want) % 2048
-                    if size > 0:
-                        stream = stream[:size]
-                batch.add(stream, w, n, out_align=1)
-                pages.append((stream, w, n))
-            data, descs, out_values = batch.finish()
-            got, status = ctx.decode_batch_host(data, descs, out_values)
-            for k, (stream, w, n) in enumerate(pages):
-                st_o, exp = oracle.hybrid_rle_decode(stream, w, n)
-                if status[k] != st_o:
-                    raise SystemExit("%s: batch %d page %d: status %d, oracle %d (w=%d n=%d len=%d)" %
-                                     (schedule, b, k, status[k], st_o, w, n, stream.size))
-                if st_o == OK:
-                    o = int(descs[k]["out_off"])
-                    bad = np.nonzero(got[o:o + n] != exp)[0]
-                    if bad.size:
-                        raise SystemExit("%s: batch %d page %d (w=%d n=%d len=%d): first mismatch at %d: %d, oracle %d" %
-                                         (schedule, b, k, w, n, stream.size, bad[0], got[o + bad[0]], exp[bad[0]]))
-                else:
-                    not_ok += 1
-                values_done += n
-            pages_done += n_pages
+        try:
+            pages_done, values_done, not_ok = fuzz(ctx, oracle, schedule, batches, seed, edges)
+        except AssertionError as e:
+            raise SystemExit(str(e))
         print("%-6s %d batches, %d pages, %d values, %d pages with a status other than ok: all as the oracle" %
               (schedule, batches, pages_done, values_done, not_ok), flush=True)
     ctx.close()

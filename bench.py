@@ -18,9 +18,18 @@ JSON line with the same fields):
     --workload bitunpack    configs[0]: bitpacked::Decoder<u32> over 2^20 values at every width 1..32 (and over
                             2^26 values, where the launch no longer dominates), next to the CPU port per width
 
+With no --workload the line is the default workload's, and it carries the other single-GPU BASELINE configs under
+"other_configs" (definition levels 10 000 x 65 536; adversarial pages at widths 3 / 17 / 31; 64 index pages, the batch
+size SURVEY quotes config 2 on; the 75 / 25 page mix of configs[4]; bit-unpack at every width), each with its step
+time, rate, dominant kernel and roofline fraction.  --no-other-configs leaves them out (A/B runs, counter passes).
+
+Before anything is timed, every distinct page of a batch is decoded by the CPU oracle (oracle/: the plain-C
+restatement of the reference decoder) and the GPU's output of every page of the batch has to be identical to it.
+
 With N > 1 the script runs under torch.distributed.run, one rank per GPU; every rank decodes its own shard of the
 global page list (pq2_partition_pages), there is no data-path collective, and the reported value is the whole-job
-rate (all ranks' output bytes / slowest rank's time).  Rank 0 prints one JSON line.
+rate (all ranks' output bytes / slowest rank's time).  Rank 0 prints one JSON line (the default workload, with the
+configs[4] page mix under "other_configs").
 """
 import argparse
 import json
@@ -53,8 +62,10 @@ def parse_args():
     ap.add_argument("--distinct", type=int, default=256,
                     help="distinct generated pages of each kind (replicated on the device); every page has its own "
                          "run lengths, so the header walks of a batch are not in lock-step")
-    ap.add_argument("--workload", default="dict",
-                    choices=["dict", "def", "adversarial", "bitpacked", "mixed5", "bitunpack"])
+    ap.add_argument("--workload", default=None,
+                    choices=["dict", "def", "adversarial", "bitpacked", "mixed5", "bitunpack"],
+                    help="one workload only (default: dict, with the other configs' results under other_configs)")
+    ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-path", action="store_true",
                     help="time pq2_decode_batch_host instead (page-locked host buffers in, host buffers out: the "
@@ -78,6 +89,11 @@ def cpu_model():
     return "unknown"
 
 
+def host_cpus():
+    """(CPUs of the machine, CPUs this process may run on)."""
+    return os.cpu_count() or 1, len(os.sched_getaffinity(0))
+
+
 def make_pool(kind, count, values, bits):
     """`count` different pages of one kind: list of (stream ndarray, expected values ndarray, bit width)."""
     pool = []
@@ -97,7 +113,18 @@ def make_pool(kind, count, values, bits):
     return pool
 
 
+_ORACLE = None
+
+
 def load_oracle():
+    """(the oracle, the flags it was built with); built once per process."""
+    global _ORACLE
+    if _ORACLE is None:
+        _ORACLE = _build_oracle()
+    return _ORACLE
+
+
+def _build_oracle():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _oracle
 
@@ -151,6 +178,7 @@ def cpu_baseline(sample, seconds, what):
         "sample": "%d pages of the workload (%s), C port of HybridRleDecoder drained per value (%s), best of %d passes"
                   % (len(sample), what, flags, reps_done),
         "all_threads": {"value": round(many, 3), "cores": n_thr},
+        "host_cpus": host_cpus()[0], "cpus_this_process_may_use": host_cpus()[1],
     }
 
 
@@ -244,49 +272,36 @@ def bench_bitunpack(args, dev, ctx, stream):
                                 "sample": "2^20 values per width, C port of bitpacked::Decoder<u32> drained per "
                                           "value (%s), mean over widths 1..32 of 5 passes each" % flags,
                                 "gbs_out_by_width": cpu}
-    print(json.dumps(line), flush=True)
+    return line
 
 
-def main():
-    args = parse_args()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+NAMES = {"dict": "RLE_DICTIONARY index pages (BASELINE configs[1]): %d pages/GPU x %d values, bit width %s, "
+                 "mixed RLE/bit-packed runs",
+         "def": "definition levels (BASELINE configs[2]): %d pages/GPU x %d values, bit width %s, long RLE "
+                "runs, 5 %% nulls in bursts",
+         "adversarial": "adversarial short runs (BASELINE configs[3]): %d pages/GPU x %d values, bit width %s, "
+                        "alternating 1-8-value RLE runs and one-group bit-packed runs",
+         "bitpacked": "pages of one bit-packed run (the reference's encoder): %d pages/GPU x %d values, bit "
+                      "width %s",
+         "mixed5": "page mix of BASELINE configs[4]: %d pages/GPU x %d values, 75 %% dictionary-index pages "
+                   "and 25 %% definition-level pages (bit widths %s)"}
+
+
+def run_pages(a, env):
+    """One workload of pages (`a`: workload, pages, values, bits, distinct, steps, warmup and the switches of
+    parse_args) on this rank's GPU; rank 0 gets the result line, the others None."""
+    ctx, dev, stream = env["ctx"], env["dev"], env["stream"]
+    rank, world, dist, backend = env["rank"], env["world"], env["dist"], env["backend"]
     distributed = world > 1
-    # PQ2_BENCH_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks (ranks share GPUs)
-    backend = os.environ.get("PQ2_BENCH_BACKEND", "nccl")
-    if backend != "nccl":
-        local_rank %= max(torch.cuda.device_count(), 1)
-    if distributed:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
-    elif args.gpus != 1:
-        print("bench.py: --gpus %d needs `python -m torch.distributed.run --nproc-per-node %d ...`" %
-              (args.gpus, args.gpus), file=sys.stderr)
-        sys.exit(2)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    ctx = Context(local_rank)
-    stream = torch.cuda.current_stream().cuda_stream
-
-    if args.workload == "bitunpack":
-        bench_bitunpack(args, dev, ctx, stream)
-        ctx.close()
-        return
-
-    n = args.values
-    total_pages = world * args.pages
-    distinct = max(1, min(args.distinct, total_pages))
+    n = a.values
+    total_pages = world * a.pages
+    distinct = max(1, min(a.distinct, total_pages))
     # pools of distinct pages; `kind_of[g]` = pool of global page g, `slot_of[g]` = its entry of that pool
-    if args.workload == "mixed5":  # every fourth page holds definition levels, the others dictionary indices
-        pools = [make_pool("dict", distinct, n, args.bits), make_pool("def", max(1, distinct // 4), n, 1)]
+    if a.workload == "mixed5":  # every fourth page holds definition levels, the others dictionary indices
+        pools = [make_pool("dict", distinct, n, a.bits), make_pool("def", max(1, distinct // 4), n, 1)]
         kind_of = np.where(np.arange(total_pages) % 4 == 3, 1, 0)
     else:
-        pools = [make_pool(args.workload, distinct, n, args.bits)]
+        pools = [make_pool(a.workload, distinct, n, a.bits)]
         kind_of = np.zeros(total_pages, dtype=np.int64)
     slot_of = np.zeros(total_pages, dtype=np.int64)
     for k, pool in enumerate(pools):
@@ -322,7 +337,7 @@ def main():
     out_bytes = 4 * my_pages * n
     bits_label = "/".join(str(b) for b in sorted(set(int(b) for b in descs["num_bits"]), reverse=True))
 
-    if args.host_path:  # end to end, host memory to host memory
+    if a.host_path:  # end to end, host memory to host memory
         h_in_t = torch.empty(d_in.numel(), dtype=torch.uint8, pin_memory=True)
         h_in_t.copy_(d_in.reshape(-1).cpu())
         h_out_t = torch.zeros(my_pages * n, dtype=torch.int32, pin_memory=True)
@@ -331,25 +346,23 @@ def main():
         for i in range(min(my_pages, 2 * len(flat))):
             assert np.array_equal(h_out_np[i * n:(i + 1) * n], flat[flat_of[lo + i]][1]), "host path differs"
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(a.steps):
             _, status = ctx.decode_batch_host(h_in_np, descs, my_pages * n, out=h_out_np)
         elapsed = time.perf_counter() - t0
         assert (status == 0).all()
-        print(json.dumps({
+        return {
             "metric": "host-to-host hybrid-RLE/bitpack decode GB/s (output bytes), copies included",
-            "value": round(out_bytes * args.steps / elapsed / 1e9, 2), "unit": "GB/s", "n_gpus": 1,
-            "steps": args.steps, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "value": round(out_bytes * a.steps / elapsed / 1e9, 2), "unit": "GB/s", "n_gpus": 1,
+            "steps": a.steps, "ms_per_step": round(1e3 * elapsed / a.steps, 3),
             "bytes_over_pcie_per_step": int(d_in.numel()) + out_bytes,
-            "pcie_gbs": round((d_in.numel() + out_bytes) * args.steps / elapsed / 1e9, 2),
+            "pcie_gbs": round((d_in.numel() + out_bytes) * a.steps / elapsed / 1e9, 2),
             "config": {"workload": "%s: %d pages x %d values, bit width %s, page-locked host buffers" %
-                       (args.workload, my_pages, n, bits_label)}}), flush=True)
-        ctx.close()
-        return
+                       (a.workload, my_pages, n, bits_label)}}
 
-    if args.gather_bytes:  # decode + dictionary gather, device-resident
+    if a.gather_bytes:  # decode + dictionary gather, device-resident
         from parquet2_amd import DICT_REF_DTYPE
         bits = int(descs["num_bits"][0])
-        words = args.gather_bytes // 4
+        words = a.gather_bytes // 4
         table = torch.randint(-2**31, 2**31 - 1, ((1 << bits) * words,), dtype=torch.int32, device=dev)
         refs = np.zeros(my_pages, dtype=DICT_REF_DTYPE)
         refs["dict_len"] = 1 << bits
@@ -357,7 +370,7 @@ def main():
 
         def gstep(want_status=False):
             return ctx.decode_dict_batch_device(d_in.data_ptr(), d_in.numel(), descs, table.data_ptr(),
-                                                table.numel() * 4, refs, args.gather_bytes, d_val.data_ptr(),
+                                                table.numel() * 4, refs, a.gather_bytes, d_val.data_ptr(),
                                                 my_pages * n, stream, want_status=want_status)
 
         assert (gstep(True) == 0).all()
@@ -365,46 +378,52 @@ def main():
         for i in range(min(my_pages, 16)):
             idx = torch.from_numpy(flat[flat_of[lo + i]][1].astype(np.int64)).to(dev)
             assert torch.equal(d_val.view(my_pages, n, words)[i], t2[idx]), "gathered values differ on page %d" % i
-        for _ in range(args.warmup):
+        for _ in range(a.warmup):
             gstep()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(a.steps):
             gstep()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
-        vbytes = my_pages * n * args.gather_bytes
-        print(json.dumps({
+        vbytes = my_pages * n * a.gather_bytes
+        return {
             "metric": "device-resident dictionary decode + gather GB/s (value bytes out)",
-            "value": round(vbytes * args.steps / elapsed / 1e9, 2), "unit": "GB/s", "n_gpus": 1, "steps": args.steps,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 4),
-            "values_per_second": round(my_pages * n * args.steps / elapsed / 1e9, 3),
+            "value": round(vbytes * a.steps / elapsed / 1e9, 2), "unit": "GB/s", "n_gpus": 1, "steps": a.steps,
+            "ms_per_step": round(1e3 * elapsed / a.steps, 4),
+            "values_per_second": round(my_pages * n * a.steps / elapsed / 1e9, 3),
             "config": {"workload": "%s: %d pages x %d values, bit width %d, %d-byte dictionary values" %
-                       (args.workload, my_pages, n, bits, args.gather_bytes)}}), flush=True)
-        ctx.close()
-        return
+                       (a.workload, my_pages, n, bits, a.gather_bytes)}}
 
     def step(want_status=False):
         return ctx.decode_batch_device(d_in.data_ptr(), d_in.numel(), descs, d_out.data_ptr(), my_pages * n, stream,
                                        want_status=want_status)
 
-    # ---- parity gate: every page of the batch must equal the generator's values ------------------------
-    if not args.no_parity:  # kernel-timing experiments with builds that do not write results
+    # ---- parity gate: every distinct page of this rank's batch decoded by the CPU oracle; the GPU's output of
+    # every page of the batch has to be identical to it --------------------------------------------------------
+    gate = None
+    if not a.no_parity:  # (skipped only by kernel-timing experiments with builds that do not write results)
+        orc, _ = load_oracle()
         status = step(want_status=True)
         assert (status == 0).all(), "non-OK page status"
         out2d = d_out.view(my_pages, n)
         first_of = {}
         for i in range(my_pages):
             f = int(flat_of[lo + i])
-            if f not in first_of:  # the first replica of a distinct page against the generator's values ...
+            if f not in first_of:  # the first replica of a distinct page against the oracle's values ...
                 first_of[f] = i
-                expect = torch.from_numpy(flat[f][1].view(np.int32)).to(dev)
-                assert torch.equal(out2d[i], expect), "GPU output differs from the expected values on page %d" % i
+                stream_f, vals_f, bits_f = flat[f]
+                st_o, want = orc.hybrid_rle_decode(stream_f, bits_f, n)
+                assert st_o == 0 and np.array_equal(want, vals_f), "oracle and generator differ on distinct page %d" % f
+                expect = torch.from_numpy(want.view(np.int32)).to(dev)
+                assert torch.equal(out2d[i], expect), "GPU output differs from the oracle's on page %d" % i
             else:  # ... every other replica against the first
                 assert torch.equal(out2d[i], out2d[first_of[f]]), "replica %d differs" % i
         expect = None
+        gate = "%d pages: %d distinct ones byte-identical to the CPU oracle, every replica to its first" % (
+            my_pages, len(first_of))
 
-    for _ in range(args.warmup):
+    for _ in range(a.warmup):
         step()
     ctx.enable_profiling(True)
     torch.cuda.synchronize()
@@ -412,7 +431,7 @@ def main():
         dist.barrier()
         torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(a.steps):
         step()
     torch.cuda.synchronize()
     if distributed:
@@ -435,62 +454,138 @@ def main():
         total_out_bytes = float(tot.item())
     else:
         total_out_bytes = float(out_bytes)
+    del d_in, d_out
+    if rank != 0:
+        return None
 
-    if rank == 0:
-        ms_per_step = 1e3 * elapsed / args.steps
-        value = total_out_bytes * args.steps / elapsed / 1e9
-        # a batch is decoded in `rounds` launches of the kernel that writes the values (one, except for batches of
-        # few large pages, which go through parse_kernel + expand_kernel in rounds)
-        rounds = max(expand_launches // max(batches, 1), 1)
-        expand_avg_ms = expand_ms / max(expand_launches, 1)
-        bytes_per_launch = (in_bytes_alg + out_bytes) / rounds
-        scouted = "+" in schedule
-        if scouted:
-            # the header walk (seven small launches) and the expansion are the hot path together: priced as one unit
-            kernel_name = schedule
-            expand_avg_ms = (parse_ms + expand_ms) / max(batches, 1)
-        achieved = bytes_per_launch / (expand_avg_ms * 1e-3) / 1e9
-        workload_key = {"workload": args.workload, "pages_per_gpu": args.pages, "values_per_page": n,
-                        "num_bits": args.bits if args.workload != "def" else 1}
-        traffic, traffic_source = traffic_from_profiles(workload_key, kernel_name)
-        names = {"dict": "RLE_DICTIONARY index pages (BASELINE configs[1]): %d pages/GPU x %d values, bit width %s, "
-                         "mixed RLE/bit-packed runs",
-                 "def": "definition levels (BASELINE configs[2]): %d pages/GPU x %d values, bit width %s, long RLE "
-                        "runs, 5 %% nulls in bursts",
-                 "adversarial": "adversarial short runs (BASELINE configs[3]): %d pages/GPU x %d values, bit width %s, "
-                                "alternating 1-8-value RLE runs and one-group bit-packed runs",
-                 "bitpacked": "pages of one bit-packed run (the reference's encoder): %d pages/GPU x %d values, bit "
-                              "width %s",
-                 "mixed5": "page mix of BASELINE configs[4]: %d pages/GPU x %d values, 75 %% dictionary-index pages "
-                           "and 25 %% definition-level pages (bit widths %s)"}
-        result = {
-            "metric": METRIC, "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {
-                "workload": names[args.workload] % (args.pages, n, bits_label),
-                "pages_per_gpu": args.pages, "values_per_page": n, "num_bits": bits_label,
-                "distinct_pages": len(flat),
-                "encoded_bytes_per_gpu": in_bytes_alg, "decoded_bytes_per_gpu": out_bytes,
-                "sharding": "pages partitioned across ranks, no collective",
-            },
-            "roofline": {
-                "bound": "hbm", "kernel": kernel_name, "schedule": schedule, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "traffic_source": traffic_source,
-                "algorithmic_bytes_per_launch": int(bytes_per_launch),
-                "avg_launch_ms": round(expand_avg_ms, 4), "launches_per_step": rounds,
-                "parse_kernel_ms_per_step": round(parse_ms / max(batches, 1), 4),
-                "%s_ms_per_step" % schedule.split("+")[-1]: round(expand_ms / max(batches, 1), 4),
-            },
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            # a bounded sample of the same pages: about cpu_seconds of decoding
-            per_pool = max(1, 16 // len(pools))
-            sample = [e for pool in pools for e in pool[:per_pool]]
-            while len(sample) > 1 and sum(len(v) for _, v, _ in sample) > (16 << 20):
-                sample = sample[:len(sample) // 2]
-            result["cpu_baseline"] = cpu_baseline(sample, args.cpu_seconds, args.workload)
+    ms_per_step = 1e3 * elapsed / a.steps
+    value = total_out_bytes * a.steps / elapsed / 1e9
+    # a batch is decoded in `rounds` launches of the kernel that writes the values (one, except for batches of
+    # few large pages, which go through parse_kernel + expand_kernel in rounds)
+    rounds = max(expand_launches // max(batches, 1), 1)
+    expand_avg_ms = expand_ms / max(expand_launches, 1)
+    bytes_per_launch = (in_bytes_alg + out_bytes) / rounds
+    scouted = "+" in schedule
+    if scouted:
+        # the header walk (seven small launches) and the expansion are the hot path together: priced as one unit
+        kernel_name = schedule
+        expand_avg_ms = (parse_ms + expand_ms) / max(batches, 1)
+    achieved = bytes_per_launch / (expand_avg_ms * 1e-3) / 1e9
+    workload_key = {"workload": a.workload, "pages_per_gpu": a.pages, "values_per_page": n,
+                    "num_bits": a.bits if a.workload != "def" else 1}
+    traffic, traffic_source = traffic_from_profiles(workload_key, kernel_name)
+    result = {
+        "metric": METRIC, "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {
+            "workload": NAMES[a.workload] % (a.pages, n, bits_label),
+            "pages_per_gpu": a.pages, "values_per_page": n, "num_bits": bits_label,
+            "distinct_pages": len(flat),
+            "encoded_bytes_per_gpu": in_bytes_alg, "decoded_bytes_per_gpu": out_bytes,
+            "sharding": "pages partitioned across ranks, no collective",
+            "parity_gate": gate,
+        },
+        "roofline": {
+            "bound": "hbm", "kernel": kernel_name, "schedule": schedule, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "traffic_source": traffic_source,
+            "algorithmic_bytes_per_launch": int(bytes_per_launch),
+            "avg_launch_ms": round(expand_avg_ms, 4), "launches_per_step": rounds,
+            "parse_kernel_ms_per_step": round(parse_ms / max(batches, 1), 4),
+            "%s_ms_per_step" % schedule.split("+")[-1]: round(expand_ms / max(batches, 1), 4),
+        },
+    }
+    if world == 1 and not a.no_cpu_baseline:
+        # a bounded sample of the same pages: about cpu_seconds of decoding
+        per_pool = max(1, 16 // len(pools))
+        sample = [e for pool in pools for e in pool[:per_pool]]
+        while len(sample) > 1 and sum(len(v) for _, v, _ in sample) > (16 << 20):
+            sample = sample[:len(sample) // 2]
+        result["cpu_baseline"] = cpu_baseline(sample, a.cpu_seconds, a.workload)
+    return result
+
+
+def brief(line):
+    """What other_configs keeps of a workload's line."""
+    r = line["roofline"]
+    out = {"workload": line["config"]["workload"], "ms_per_step": line["ms_per_step"], "value": line["value"],
+           "unit": line["unit"],
+           "roofline": {k: r[k] for k in ("kernel", "achieved", "frac", "traffic", "traffic_source") if k in r}}
+    for k in ("avg_launch_ms", "launches_per_step", "algorithmic_bytes_per_launch", "note"):
+        if k in r:
+            out["roofline"][k] = r[k]
+    if "parity_gate" in line["config"]:
+        out["parity_gate"] = line["config"]["parity_gate"]
+    return out
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = world > 1
+    dist = None
+    # PQ2_BENCH_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks (ranks share GPUs)
+    backend = os.environ.get("PQ2_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(torch.cuda.device_count(), 1)
+    if distributed:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    elif args.gpus != 1:
+        print("bench.py: --gpus %d needs `python -m torch.distributed.run --nproc-per-node %d ...`" %
+              (args.gpus, args.gpus), file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    ctx = Context(local_rank)
+    stream = torch.cuda.current_stream().cuda_stream
+    env = {"ctx": ctx, "dev": dev, "stream": stream, "rank": rank, "world": world, "dist": dist, "backend": backend}
+
+    if args.workload == "bitunpack":
+        print(json.dumps(bench_bitunpack(args, dev, ctx, stream)), flush=True)
+        ctx.close()
+        return
+
+    others = args.workload is None and not args.no_other_configs and not args.host_path and not args.gather_bytes
+    if args.workload is None:
+        args.workload = "dict"
+    result = run_pages(args, env)
+    if others:
+        def sub(**kw):
+            a = argparse.Namespace(**vars(args))
+            a.no_cpu_baseline = True
+            for k, v in kw.items():
+                setattr(a, k, v)
+            return a
+
+        # the other BASELINE configs (one GPU: all of them; several ranks: the page mix configs[4] names)
+        cases = [sub(workload="mixed5")]
+        if world == 1:
+            cases = [sub(workload="def", pages=10000, values=65536, bits=1),
+                     sub(workload="adversarial", pages=16, bits=3), sub(workload="adversarial", pages=16, bits=17),
+                     sub(workload="adversarial", pages=16, bits=31), sub(workload="dict", pages=64)] + cases
+        lines = []
+        for a in cases:
+            torch.cuda.empty_cache()
+            line = run_pages(a, env)
+            if line is not None:
+                lines.append(brief(line))
+        if world == 1:
+            torch.cuda.empty_cache()
+            b = argparse.Namespace(**vars(args))
+            b.no_cpu_baseline = True
+            b.steps = min(args.steps, 10)
+            lines.append(brief(bench_bitunpack(b, dev, ctx, stream)))
+        if result is not None:
+            result["other_configs"] = lines
+    if result is not None:
         print(json.dumps(result), flush=True)
     ctx.close()
     if distributed:

@@ -8,5 +8,5 @@ while read -r variant envs args; do
   echo "case $variant $envs $args" >> $out
   ( [ "$variant" != "-" ] && export PQ2_LIB=$GRAFT_REPO_ROOT/parquet2_amd/lib/variants/libpq2hip_$variant.so
     [ "$envs" != "-" ] && for kv in ${envs//:/ }; do export "$kv"; done
-    timeout -k 10 120 python3 bench.py --no-cpu-baseline --steps 20 --warmup 3 $args 2>&1 | grep '^{' >> $out ) || { echo FAILED >> $out; exit 1; }
+    timeout -k 10 120 python3 bench.py --no-cpu-baseline --no-other-configs --steps 20 --warmup 3 $args 2>&1 | grep '^{' >> $out ) || { echo FAILED >> $out; exit 1; }
 done < $GRAFT_REPO_ROOT/tools/ab_cases.txt

@@ -10,5 +10,5 @@ for vb in 4 8 12; do
   done
 done
 echo "== index path, ring of 16 KiB / default (2048 pages)" >> $OUT
-PQ2_RING_BYTES=16384 timeout -k 10 200 python bench.py --no-cpu-baseline --steps 20 --warmup 3 >> $OUT 2>> gpurun_out/gather_bench.err || exit 1
-timeout -k 10 200 python bench.py --no-cpu-baseline --steps 20 --warmup 3 >> $OUT 2>> gpurun_out/gather_bench.err || exit 1
+PQ2_RING_BYTES=16384 timeout -k 10 200 python bench.py --no-cpu-baseline --no-other-configs --steps 20 --warmup 3 >> $OUT 2>> gpurun_out/gather_bench.err || exit 1
+timeout -k 10 200 python bench.py --no-cpu-baseline --no-other-configs --steps 20 --warmup 3 >> $OUT 2>> gpurun_out/gather_bench.err || exit 1

@@ -8,7 +8,7 @@ OUT=gpurun_out/scout_bench.jsonl
 run() {  # label mode args...
     label=$1; mode=$2; shift 2
     echo "== $label mode=$mode" >> $OUT
-    PQ2_MODE=$mode timeout -k 10 120 python bench.py --no-cpu-baseline --steps 20 --warmup 3 "$@" >> $OUT 2>> gpurun_out/scout_bench.err
+    PQ2_MODE=$mode timeout -k 10 120 python bench.py --no-cpu-baseline --no-other-configs --steps 20 --warmup 3 "$@" >> $OUT 2>> gpurun_out/scout_bench.err
 }
 for w in 3 17 31; do
     run adv$w scout --workload adversarial --pages 16 --bits $w --distinct 16

@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 run_case() {  # name, bench args...
   name=$1; shift
   timeout -k 10 300 python3 $R/bench.py "$@" > $O/bench_$name.json 2> $O/bench_$name.err || return 1
-  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$name -- python3 $R/bench.py --no-cpu-baseline --steps 5 "$@" > $O/stats_$name.log 2>&1 || return 1
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$name -- python3 $R/bench.py --no-cpu-baseline --no-other-configs --steps 5 "$@" > $O/stats_$name.log 2>&1 || return 1
   cp $(find $O/stats_$name -name '*kernel_stats.csv' | head -1) $O/kernel_stats_$name.csv
   rm -rf $O/stats_$name
 }
@@ -23,8 +23,8 @@ run_case dict64 --pages 64 || exit 1
 run_case bitpacked12 --workload bitpacked --pages 1024 || exit 1
 run_case mixed5 --workload mixed5 || exit 1
 run_case bitunpack --workload bitunpack --steps 10 || exit 1
-timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --no-cpu-baseline --steps 2 --warmup 1 > $O/pmc_fetch.log 2>&1 || exit 1
-timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py --no-cpu-baseline --steps 2 --warmup 1 > $O/pmc_write.log 2>&1 || exit 1
+timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --no-cpu-baseline --no-other-configs --steps 2 --warmup 1 > $O/pmc_fetch.log 2>&1 || exit 1
+timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py --no-cpu-baseline --no-other-configs --steps 2 --warmup 1 > $O/pmc_write.log 2>&1 || exit 1
 timeout -k 10 200 python3 $R/bench.py --host-path --pages 512 --steps 5 > $O/host_path.json 2> $O/host_path.err || exit 1
 # dictionary values: the lookup inside ring_kernel against the two passes, bench lines and memory-side traffic (4-byte values)
 run_case def64 --workload def --pages 64 --values 65536 || exit 1

@@ -11,6 +11,8 @@ JSON line with the same fields):
 
     --workload def          configs[2]: definition levels, bit width 1, long RLE runs, 5 % nulls
                             (use --pages 10000 --values 65536)
+    --workload defbits      the same pages decoded as DefLevelsDecoder::Bitmap has them: one validity bit per row
+                            (pq2_decode_validity_bitmap_batch_device), with a roofline of its own
     --workload adversarial  configs[3]: alternating 1-8-value RLE runs and one-group bit-packed runs
                             (use --pages 16 --bits 3|17|31)
     --workload bitpacked    pages as the reference's own encoder writes them: one bit-packed run
@@ -63,7 +65,7 @@ def parse_args():
                     help="distinct generated pages of each kind (replicated on the device); every page has its own "
                          "run lengths, so the header walks of a batch are not in lock-step")
     ap.add_argument("--workload", default=None,
-                    choices=["dict", "def", "adversarial", "bitpacked", "mixed5", "bitunpack"],
+                    choices=["dict", "def", "defbits", "adversarial", "bitpacked", "mixed5", "bitunpack"],
                     help="one workload only (default: dict, with the other configs' results under other_configs)")
     ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -100,7 +102,7 @@ def make_pool(kind, count, values, bits):
     for p in range(count):
         if kind == "dict":
             s, v = synth.dict_page(synth.seed_for(2, p), values, bits)
-        elif kind == "def":
+        elif kind in ("def", "defbits"):
             s, v = synth.def_levels_page(synth.seed_for(3, p), values)
             bits = 1
         elif kind == "adversarial":
@@ -279,6 +281,8 @@ NAMES = {"dict": "RLE_DICTIONARY index pages (BASELINE configs[1]): %d pages/GPU
                  "mixed RLE/bit-packed runs",
          "def": "definition levels (BASELINE configs[2]): %d pages/GPU x %d values, bit width %s, long RLE "
                 "runs, 5 %% nulls in bursts",
+         "defbits": "definition levels (BASELINE configs[2]) as validity bitmaps, one bit per row "
+                    "(DefLevelsDecoder::Bitmap): %d pages/GPU x %d rows, bit width %s",
          "adversarial": "adversarial short runs (BASELINE configs[3]): %d pages/GPU x %d values, bit width %s, "
                         "alternating 1-8-value RLE runs and one-group bit-packed runs",
          "bitpacked": "pages of one bit-packed run (the reference's encoder): %d pages/GPU x %d values, bit "
@@ -329,12 +333,14 @@ def run_pages(a, env):
     my_flat = torch.from_numpy(flat_of[lo:hi]).to(dev)
     d_in = d_flat[my_flat].contiguous()  # [my_pages, stride]
     del d_flat
-    d_out = torch.empty(my_pages * n, dtype=torch.int32, device=dev)
+    as_bits = a.workload == "defbits"  # one validity bit per row instead of one u32 per value
+    assert not as_bits or n % 32 == 0
+    d_out = torch.empty(my_pages * n // 32 if as_bits else my_pages * n, dtype=torch.int32, device=dev)
     descs = g_descs[lo:hi].copy()
     descs["in_off"] = np.arange(my_pages, dtype=np.uint64) * stride
-    descs["out_off"] = np.arange(my_pages, dtype=np.uint64) * n
+    descs["out_off"] = np.arange(my_pages, dtype=np.uint64) * (n // 8 if as_bits else n)  # bytes | values
     in_bytes_alg = int(descs["in_len"].sum())
-    out_bytes = 4 * my_pages * n
+    out_bytes = my_pages * n // 8 if as_bits else 4 * my_pages * n
     bits_label = "/".join(str(b) for b in sorted(set(int(b) for b in descs["num_bits"]), reverse=True))
 
     if a.host_path:  # end to end, host memory to host memory
@@ -396,6 +402,10 @@ def run_pages(a, env):
                        (a.workload, my_pages, n, bits, a.gather_bytes)}}
 
     def step(want_status=False):
+        if as_bits:
+            r = ctx.decode_validity_bitmap_batch_device(d_in.data_ptr(), d_in.numel(), descs, d_out.data_ptr(),
+                                                        out_bytes, stream, want_counts=want_status)
+            return r[2] if want_status else None
         return ctx.decode_batch_device(d_in.data_ptr(), d_in.numel(), descs, d_out.data_ptr(), my_pages * n, stream,
                                        want_status=want_status)
 
@@ -406,7 +416,7 @@ def run_pages(a, env):
         orc, _ = load_oracle()
         status = step(want_status=True)
         assert (status == 0).all(), "non-OK page status"
-        out2d = d_out.view(my_pages, n)
+        out2d = d_out.view(my_pages, n // 32 if as_bits else n)
         first_of = {}
         for i in range(my_pages):
             f = int(flat_of[lo + i])
@@ -415,6 +425,8 @@ def run_pages(a, env):
                 stream_f, vals_f, bits_f = flat[f]
                 st_o, want = orc.hybrid_rle_decode(stream_f, bits_f, n)
                 assert st_o == 0 and np.array_equal(want, vals_f), "oracle and generator differ on distinct page %d" % f
+                if as_bits:  # the levels of a flat nullable column are its validity: row r at bit r % 8 of byte r / 8
+                    want = np.packbits(want.astype(np.uint8), bitorder="little").view(np.uint32)
                 expect = torch.from_numpy(want.view(np.int32)).to(dev)
                 assert torch.equal(out2d[i], expect), "GPU output differs from the oracle's on page %d" % i
             else:  # ... every other replica against the first
@@ -472,12 +484,14 @@ def run_pages(a, env):
         expand_avg_ms = (parse_ms + expand_ms) / max(batches, 1)
     achieved = bytes_per_launch / (expand_avg_ms * 1e-3) / 1e9
     workload_key = {"workload": a.workload, "pages_per_gpu": a.pages, "values_per_page": n,
-                    "num_bits": a.bits if a.workload != "def" else 1}
+                    "num_bits": a.bits if a.workload not in ("def", "defbits") else 1}
     traffic, traffic_source = traffic_from_profiles(workload_key, kernel_name)
     result = {
-        "metric": METRIC, "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": a.steps,
+        "metric": "device-resident validity-bitmap decode, 10^9 rows/s (DefLevelsDecoder::Bitmap)" if as_bits else METRIC,
+        "value": round(value * 8 if as_bits else value, 2), "unit": "Grows/s" if as_bits else "GB/s", "n_gpus": world,
+        "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": "u1" if as_bits else "u32", "data": "synthetic",
         "config": {
             "workload": NAMES[a.workload] % (a.pages, n, bits_label),
             "pages_per_gpu": a.pages, "values_per_page": n, "num_bits": bits_label,
@@ -496,7 +510,7 @@ def run_pages(a, env):
             "%s_ms_per_step" % schedule.split("+")[-1]: round(expand_ms / max(batches, 1), 4),
         },
     }
-    if world == 1 and not a.no_cpu_baseline:
+    if world == 1 and not a.no_cpu_baseline and not as_bits:  # (the port that is timed expands levels to u32)
         # a bounded sample of the same pages: about cpu_seconds of decoding
         per_pool = max(1, 16 // len(pools))
         sample = [e for pool in pools for e in pool[:per_pool]]
@@ -569,6 +583,7 @@ def main():
         cases = [sub(workload="mixed5")]
         if world == 1:
             cases = [sub(workload="def", pages=10000, values=65536, bits=1),
+                     sub(workload="defbits", pages=10000, values=65536, bits=1),
                      sub(workload="adversarial", pages=16, bits=3), sub(workload="adversarial", pages=16, bits=17),
                      sub(workload="adversarial", pages=16, bits=31), sub(workload="dict", pages=64)] + cases
         lines = []

@@ -194,6 +194,35 @@ int32_t pq2_decode_batch_device_noalloc(int32_t device_id, const void *d_in, uin
                                         const pq2_page_desc *d_descs, uint64_t n_pages, uint32_t max_bits,
                                         uint32_t *d_out, uint64_t out_values, int32_t *d_status, void *stream);
 
+/* ---- definition levels of flat nullable columns: validity bitmaps ----------- */
+
+/* DefLevelsDecoder::Bitmap made whole.  For max_def_level == 1 the reference
+ * never expands levels: DefLevelsDecoder::try_new
+ * (src/deserialize/utils.rs:41-48) wraps the run iterator in HybridRleIter
+ * (src/deserialize/hybrid_rle.rs:54-115), which hands the consumer
+ * Bitmap(slice, len) for a bit-packed run (len = min(slice.len() * 8,
+ * remaining), :97-105) and Repeated(value[0] == 1, min(run, remaining)) for an
+ * RLE run (:106-113), and the consumer appends them to its validity bitmap.
+ * This call does that for a batch of pages on the device: page i's level
+ * stream (descs[i]: num_bits must be 1, num_values = the page's rows) becomes
+ * a bitmap at d_bitmap + descs[i].out_off -- out_off counts BYTES here and is a
+ * multiple of 4 -- with row r at bit r % 8 of byte r / 8 (LSB first, as
+ * BitmapIter reads, src/encoding/hybrid_rle/bitmap.rs:46-62), written in whole
+ * 32-bit words (a page takes 4 * ceil(num_values / 32) bytes; the bits behind
+ * its last row are 0).
+ * The iterator ends with the stream (hybrid_rle.rs:90-94: no zero padding,
+ * unlike HybridRleDecoder): rows[i] receives the rows the stream holds (at most
+ * num_values; the bits of the rows behind them are 0) and set_counts[i] the
+ * number of set bits, i.e. of valid rows.  Either may be NULL.  An RLE run
+ * whose value byte is not 1 repeats `false`, whatever its low bit (:107-108).
+ * Statuses as pq2_decode_batch_device (only the 10-byte varint of
+ * uleb128.rs:10-12 can fail a one-bit stream).  If rows, set_counts or status
+ * is non-NULL the call waits for the batch. */
+int32_t pq2_decode_validity_bitmap_batch_device(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes,
+                                                const pq2_page_desc *descs, uint64_t n_pages, void *d_bitmap,
+                                                uint64_t bitmap_bytes, uint32_t *rows, uint32_t *set_counts,
+                                                int32_t *status, void *stream);
+
 /* ---- dictionary pages: indices -> values ---------------------------------- */
 
 /* Where a page's dictionary lies inside the dictionary buffer: `dict_len`

@@ -74,6 +74,9 @@ SIGNATURES = {
     "pq2_fetch_status": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "pq2_decode_batch_device_noalloc": (C.c_int32, [C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
                                                      C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "pq2_decode_validity_bitmap_batch_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+                                                             C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                             C.c_void_p]),
     "pq2_decode_dict_batch_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p,
                                                   C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p,
                                                   C.c_void_p]),
@@ -224,6 +227,23 @@ class Context:
                                            ptr(status) if want_status else None, C.c_void_p(stream))
         self._check(st)
         return status
+
+    def decode_validity_bitmap_batch_device(self, d_in_ptr, in_bytes, descs, d_bitmap_ptr, bitmap_bytes, stream=0,
+                                            want_counts=True):
+        """One-bit definition levels -> validity bitmaps on the device (pq2_decode_validity_bitmap_batch_device;
+        descs' out_off counts bytes of the bitmap buffer).  Returns (rows, set_counts, statuses), or None when
+        want_counts is false (the call then only enqueues)."""
+        descs = np.ascontiguousarray(descs, dtype=PAGE_DESC_DTYPE)
+        n = len(descs)
+        rows = np.zeros(n, dtype=np.uint32) if want_counts else None
+        sets = np.zeros(n, dtype=np.uint32) if want_counts else None
+        status = np.zeros(n, dtype=np.int32) if want_counts else None
+        st = lib().pq2_decode_validity_bitmap_batch_device(
+            self._h, C.c_void_p(d_in_ptr), in_bytes, ptr(descs), n, C.c_void_p(d_bitmap_ptr), bitmap_bytes,
+            ptr(rows) if want_counts else None, ptr(sets) if want_counts else None,
+            ptr(status) if want_counts else None, C.c_void_p(stream))
+        self._check(st)
+        return (rows, sets, status) if want_counts else None
 
     def decode_dict_batch_device(self, d_in_ptr, in_bytes, descs, d_dict_ptr, dict_bytes, dict_refs, value_size,
                                  d_out_ptr, out_values, stream=0, want_status=True):

@@ -51,6 +51,8 @@ hipError_t pq2_launch_ring(const void *pages, uint32_t n_pages, int32_t *status,
 uint32_t pq2_ring_ticket_bytes();
 uint32_t pq2_ring_dict_max_bits();  // pq2_ring_dict.hip
 uint32_t pq2_ring_dict_max_bytes();
+hipError_t pq2_launch_ring_bits(const void *pages, uint32_t n_pages, int32_t *status, uint32_t *cu_tickets, uint32_t epoch,
+                                uint32_t *bit_meta, hipStream_t stream);  // pq2_ring.hip
 hipError_t pq2_launch_ring_dict(const void *pages, uint32_t n_pages, int32_t *status, uint32_t *cu_tickets,
                                 uint32_t epoch, const uint32_t *tile_mask, const void *dicts, uint32_t value_words, uint32_t max_dict_bytes,
                                 hipStream_t stream);
@@ -154,6 +156,13 @@ struct FusedDict {
     uint32_t value_words, max_dict_bytes;
 };
 
+// What pq2_decode_validity_bitmap_batch_device adds to a batch: the pages come out as validity bitmaps (out_off: the
+// byte at which a page's bitmap begins) and ring_kernel reports two words per page, rows and set bits.
+struct BitmapOut {
+    uint64_t bitmap_bytes;
+    uint32_t *d_meta;
+};
+
 struct FrontJob {
     const void *d_raw;
     uint32_t n_pages;
@@ -179,6 +188,7 @@ struct pq2_ctx {
     bool last_scout = false;
     // pq2_decode_dict_batch_device: the decoded indices, and the per-page gather descriptors (page-locked + device)
     DevBuf d_indices, d_gather, d_seg_valid;
+    DevBuf d_bit_meta;  // pq2_decode_validity_bitmap_batch_device: rows and set bits of every page
     void *h_gather = nullptr;
     size_t h_gather_cap = 0;
     hipEvent_t gather_copied = nullptr;
@@ -342,7 +352,8 @@ bool auto_takes_scout(const pq2_page_desc *descs, uint64_t n_pages) {
 // them and enqueues parse + expand on `stream`.
 int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const pq2_page_desc *descs, uint64_t n_pages,
                       uint32_t *d_out, uint64_t out_values, hipStream_t stream, const FrontJob *front = nullptr,
-                      uint32_t min_max_bits = 0, const TileMask *mask = nullptr, const FusedDict *fused = nullptr) {
+                      uint32_t min_max_bits = 0, const TileMask *mask = nullptr, const FusedDict *fused = nullptr,
+                      const BitmapOut *bits = nullptr) {
     if (n_pages > 0x7fffffffull) return fail(ctx, PQ2_INVALID_PARAMETER, "too many pages in one batch");
     if (n_pages > 0 && !descs) return fail(ctx, PQ2_INVALID_PARAMETER, "descs is NULL");
     // the device-side metadata and the Resume table are shared by consecutive batches: stream order
@@ -381,11 +392,17 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
         if (d.in_off > in_bytes || d.in_len > in_bytes - d.in_off)
             return fail(ctx, PQ2_INVALID_PARAMETER, "page stream outside the input buffer");
         if (d.num_values > PQ2_MAX_PAGE_VALUES) return fail(ctx, PQ2_INVALID_PARAMETER, "page has too many values");
-        if (d.out_off > out_values || d.num_values > out_values - d.out_off)
+        if (bits) {  // out_off counts bytes of the bitmap buffer; a page's bitmap is written in whole 32-bit words
+            if (d.num_bits != 1) return fail(ctx, PQ2_INVALID_PARAMETER, "a validity bitmap takes one-bit levels (max_def_level == 1)");
+            const uint64_t page_bytes = (d.num_values + 31) / 32 * 4;
+            if ((d.out_off & 3u) != 0 || d.out_off > bits->bitmap_bytes || page_bytes > bits->bitmap_bytes - d.out_off)
+                return fail(ctx, PQ2_INVALID_PARAMETER, "page bitmap outside the bitmap buffer, or not at a multiple of 4 bytes");
+        } else if (d.out_off > out_values || d.num_values > out_values - d.out_off) {
             return fail(ctx, PQ2_INVALID_PARAMETER, "page output outside the output buffer");
+        }
         PageDev &p = pages[i];
         p.in_addr = reinterpret_cast<uint64_t>(d_in) + d.in_off;
-        p.out_addr = reinterpret_cast<uint64_t>(d_out) + d.out_off * sizeof(uint32_t);
+        p.out_addr = reinterpret_cast<uint64_t>(d_out) + (bits ? d.out_off : d.out_off * sizeof(uint32_t));
         p.in_len = d.in_len;
         p.num_values = static_cast<uint32_t>(d.num_values);
         p.num_bits = d.num_bits;
@@ -411,20 +428,20 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
     // few pages: no page's walk has another page's expansion to hide behind, so the walk itself is spread over
     // the GPU (not where the streams' addresses are only known on the device)
     if (fused && !takes_ring(ctx, n_pages)) return fail(ctx, PQ2_DEVICE_ERROR, "internal: fused lookup outside ring_kernel");
-    const bool scout = !front && !fused &&
+    const bool scout = !front && !fused && !bits &&
                        (ctx->mode == pq2_ctx::kScout || (ctx->mode == pq2_ctx::kAuto && auto_takes_scout(descs, n_pages)));
     // (a workgroup per page costs a few microseconds before the page's first value is written: pages of a few thousand
     // values, in batches that fill the GPU either way, go to parse_kernel + expand_kernel, one wave per page and one
     // per 4096 values -- 65 536 pages of 4096 values: 0.60 against 0.99 ms, 32 768 of 8192: 0.56 against 0.61,
     // 16 384 of 16 384: 0.54 against 0.46)
     bool small_pages = false;
-    if (ctx->mode == pq2_ctx::kAuto && !fused && !scout && n_pages > 1024) {
+    if (ctx->mode == pq2_ctx::kAuto && !fused && !bits && !scout && n_pages > 1024) {
         uint64_t values = 0;
         for (uint64_t i = 0; i < n_pages; ++i) values += descs[i].num_values;
         small_pages = values <= n_pages * 8192;
     }
     const bool ring = !scout && !small_pages &&
-                      (ctx->mode == pq2_ctx::kRing ||
+                      (bits != nullptr /* only ring_kernel writes bitmaps */ || ctx->mode == pq2_ctx::kRing ||
                        (ctx->mode == pq2_ctx::kAuto && (n_pages >= kFusedMinPages || (!front && !fused))));
     // (kScoutMaxPages >= kFusedMinPages: in kAuto a batch whose streams' addresses the host knows is either walked by
     // the scout kernels or takes ring_kernel)
@@ -553,12 +570,17 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
         }
         if (fused)  // the walking wave and the expanding waves merge what they report: from 0
             PQ2_HIP(ctx, hipMemsetAsync(d_status, 0, n_pages * sizeof(int32_t), stream));
+        if (bits)  // the expanding waves add up a page's set bits
+            PQ2_HIP(ctx, hipMemsetAsync(bits->d_meta, 0, n_pages * 2 * sizeof(uint32_t), stream));
         if ((st = stamped(true, stream, [&] {
                  uint32_t *const ring_tickets = static_cast<uint32_t *>(ctx->d_tickets.ptr) + pq2_cu_ticket_bytes() / 4u;
                  if (fused)
                      return pq2_launch_ring_dict(d_pages, static_cast<uint32_t>(n_pages), d_status, ring_tickets,
                                                  ctx->ring_epoch++, d_tile_mask, fused->d_dicts, fused->value_words,
                                                  fused->max_dict_bytes, stream);
+                 if (bits)
+                     return pq2_launch_ring_bits(d_pages, static_cast<uint32_t>(n_pages), d_status, ring_tickets,
+                                                 ctx->ring_epoch++, bits->d_meta, stream);
                  if (ring)
                      return pq2_launch_ring(d_pages, static_cast<uint32_t>(n_pages), d_status, ring_tickets,
                                             ctx->ring_epoch++, max_bits, d_tile_mask, stream);
@@ -613,7 +635,7 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
     ctx->last_n_pages = n_pages;
     ctx->last_scout = scout;
     ctx->last_scout_tiles = stiles;
-    ctx->last_schedule = fused ? "ring_kernel+dictionary" : ring ? "ring_kernel" : per_page ? "decode_kernel" : scout ? "scout+expand_kernel" : "expand_kernel";
+    ctx->last_schedule = fused ? "ring_kernel+dictionary" : bits ? "ring_kernel+bitmap" : ring ? "ring_kernel" : per_page ? "decode_kernel" : scout ? "scout+expand_kernel" : "expand_kernel";
     return PQ2_OK;
 }
 
@@ -685,7 +707,7 @@ int32_t pq2_ctx_destroy(pq2_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     for (DevBuf *b : {&ctx->d_meta, &ctx->d_status, &ctx->d_resume, &ctx->d_tile_page, &ctx->d_run_pos, &ctx->d_state,
-                      &ctx->d_tickets, &ctx->d_scout_table, &ctx->d_scout_words, &ctx->d_seg_valid, &ctx->d_indices, &ctx->d_gather, &ctx->d_in, &ctx->d_out})
+                      &ctx->d_tickets, &ctx->d_scout_table, &ctx->d_scout_words, &ctx->d_seg_valid, &ctx->d_bit_meta, &ctx->d_indices, &ctx->d_gather, &ctx->d_in, &ctx->d_out})
         if (b->ptr) (void)hipFree(b->ptr);
     for (hipStream_t s : {ctx->parse_stream, ctx->expand_stream[0], ctx->expand_stream[1]})
         if (s) (void)hipStreamDestroy(s);
@@ -779,6 +801,34 @@ int32_t pq2_decode_batch_device(pq2_ctx *ctx, const void *d_in, uint64_t in_byte
     ctx->pages_total += n_pages;
     int32_t st = enqueue_batch(ctx, d_in, in_bytes, descs, n_pages, d_out, out_values, static_cast<hipStream_t>(stream));
     if (st != PQ2_OK) return st;
+    if (status) return fetch_status(ctx, status, n_pages);
+    return PQ2_OK;
+}
+
+int32_t pq2_decode_validity_bitmap_batch_device(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes,
+                                                const pq2_page_desc *descs, uint64_t n_pages, void *d_bitmap,
+                                                uint64_t bitmap_bytes, uint32_t *rows, uint32_t *set_counts,
+                                                int32_t *status, void *stream_) {
+    if (!ctx) return PQ2_INVALID_PARAMETER;
+    PQ2_HIP(ctx, hipSetDevice(ctx->device));
+    if (n_pages > 0x7fffffffull) return fail(ctx, PQ2_INVALID_PARAMETER, "too many pages in one batch");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    int32_t st = reserve(ctx, ctx->d_bit_meta, std::max<uint64_t>(n_pages, 1) * 2 * sizeof(uint32_t));
+    if (st != PQ2_OK) return st;
+    const BitmapOut bits{bitmap_bytes, static_cast<uint32_t *>(ctx->d_bit_meta.ptr)};
+    st = enqueue_batch(ctx, d_in, in_bytes, descs, n_pages, static_cast<uint32_t *>(d_bitmap), 0, stream, nullptr, 0,
+                       nullptr, nullptr, &bits);
+    if (st != PQ2_OK) return st;
+    if ((rows || set_counts) && n_pages) {
+        std::vector<uint32_t> meta(n_pages * 2);
+        PQ2_HIP(ctx, hipMemcpyAsync(meta.data(), ctx->d_bit_meta.ptr, meta.size() * sizeof(uint32_t),
+                                    hipMemcpyDeviceToHost, stream));
+        PQ2_HIP(ctx, hipStreamSynchronize(stream));
+        for (uint64_t i = 0; i < n_pages; ++i) {
+            if (rows) rows[i] = meta[2 * i];
+            if (set_counts) set_counts[i] = meta[2 * i + 1];
+        }
+    }
     if (status) return fetch_status(ctx, status, n_pages);
     return PQ2_OK;
 }

@@ -183,6 +183,7 @@ struct RingShared {
     uint32_t *hq;
     Resume *rq;
     RingCtl *ctl;
+    uint32_t *rows_out;   // validity bitmaps: where the walk says how many rows the page's stream holds (else null)
 };
 
 // kMerge: the page's status is shared with the expanding waves (a dictionary index out of range): the larger
@@ -451,6 +452,8 @@ __device__ __forceinline__ void ring_walk(const PageDev &pg, const uint32_t page
         }
         if (aborted || lds_load(&ctl->abort) != 0u) return;
         set_status(st);
+        // HybridRleIter ends with the stream (src/deserialize/hybrid_rle.rs:90-94): its rows are those of the runs
+        if (sh.rows_out != nullptr && lane == 0) *sh.rows_out = min(produced, n);
         // nothing behind the walk's position is needed: the fills end there
         final_hi = min(final_hi, (floor_pos + 64u + kSlot - 1u) & ~(kSlot - 1u));
         lds_store(&ctl->final_hi, final_hi);
@@ -1206,6 +1209,195 @@ __device__ __forceinline__ void ring_expand_span(RingExpander &io, uint2 *tbl, v
     } while (lo < block_n);
 }
 
+// 32 stream bits from bit position `bit` of the ring on.
+__device__ __forceinline__ uint32_t ring_bits32(const uint8_t *ring, uint32_t bit) {
+    const uint32_t *src = (const uint32_t *)(ring + ((bit >> 3) & ~3u));
+    return __builtin_amdgcn_alignbit(src[1], src[0], bit & 31u);
+}
+
+constexpr uint32_t kRingBitsSpanValues = 4u * kBlockValues;        // a span of the bitmap mode: the whole tile
+constexpr uint32_t kRingBitsSpanWords = kRingBitsSpanValues / 32u;  // ... 128 words of validity bits
+static_assert(kRingBitsSpanWords + 16u <= RingSpan<2>::kBytes, "the word index fits the chunk index's LDS");
+
+// One wave turns the rows [span_start, span_start + block_n) of a page of one-bit definition levels into validity
+// bits, row r of the span at bit r % 32 of words[r / 32]: what a consumer of DefLevelsDecoder::Bitmap assembles from
+// the runs HybridRleIter hands it (src/deserialize/hybrid_rle.rs:90-115: a bit-packed run is a slice of the bitmap
+// as it stands, an RLE run repeats `value[0] == 1`).  ring_expand_span with words of 32 rows in place of chunks of
+// 4 values: the run table of a pass is the same, the index says which run holds each word's first row, and a lane
+// assembles one word from the runs that overlap it -- no value is ever expanded.  A pass that ends inside a word
+// hands the word's bits on to the next pass (`carry`); spans begin and end with words.
+__device__ __forceinline__ void ring_expand_span_bits(RingExpander &io, uint2 *tbl, void *cidx_lds, const Resume rs,
+                                                      const uint32_t end, const uint32_t n, const uint32_t span_start,
+                                                      const uint32_t block_n, uint32_t *__restrict__ words,
+                                                      uint32_t &set_bits, const uint32_t lane) {
+    constexpr uint32_t w = 1u;
+    constexpr uint32_t kLaneRuns = kRingTableRuns - 1;
+    uint8_t *const cidx = (uint8_t *)cidx_lds;
+    const uint8_t *const ring = io.sh.ring;
+    const uint32_t rmask = io.sh.ring_bytes - 1u;
+    const uint32_t bit_mask = io.sh.ring_bytes * 8u - 1u;
+    const uint32_t max_vals = ((io.cap - 256u) / w) * 8u;  // values of one run the ring surely holds at once
+    const uint32_t span_end = span_start + block_n;
+
+    uint32_t kind = rs.rem_kind >> 31;
+    uint32_t rem = rs.rem_kind & kRemMask;
+    uint32_t payload = rs.payload;  // RLE: the value
+    uint32_t skip = rs.skip;        // bit-packed only
+    uint32_t ridx = rs.run_index;
+    uint32_t lo = 0;
+    uint32_t carry = 0;  // the bits below row `lo` of the word that holds it
+
+    do {
+        // ---- the runs that cover [lo, hi) into the table (as ring_expand_span's phase 1) ---------------------
+        uint32_t take0 = min(rem, block_n - lo);
+        uint32_t y0 = payload;
+        bool alone = take0 == block_n - lo;
+        uint32_t from = kEndPos;  // the first stream byte this pass reads
+        if (kind == kBitpacked) {
+            const uint32_t b_lo = payload + (skip >> 3) * w;
+            if (take0 > max_vals) take0 = max_vals, alone = true;
+            from = b_lo;
+            y0 = b_lo * 8u + (skip & 7u) * w - lo * w;  // ring bit position of the span's row 0 (taken mod 8R)
+        }
+        uint32_t runs = 0;
+        if (!alone) {
+            runs = io.await_runs(ridx, span_end, false, lane);
+            if (io.aborted) return;
+        }
+        uint32_t hi = lo + take0;
+        uint32_t hp = kNotYet;
+        if (!alone && lane < kLaneRuns && ridx + 1u + lane < runs) hp = io.sh.hq[(ridx + 1u + lane) & (kHq - 1u)];
+        const uint32_t hp0 = __builtin_amdgcn_readfirstlane(hp);
+        if (kind == kRle && hp0 < kNotYet) from = hp0;
+        uint32_t avail = lds_load(&io.sh.ctl->landed);
+        if (from != kEndPos) {
+            io.raise_need(from, lane);
+            const uint32_t first_end = payload + ((skip + take0 + 7u) >> 3) * w + 8u;
+            if (kind == kBitpacked && avail < min(first_end, lds_load(&io.sh.ctl->final_hi))) {
+                io.await_bytes(first_end, lane);
+                if (io.aborted) return;
+                avail = lds_load(&io.sh.ctl->landed);
+            }
+        }
+        const uint32_t reach = io.need >= kNoNeed ? avail : min(avail, io.need + io.cap);  // bytes this pass may read
+
+        if (lane < (kRingBitsSpanWords + 16u) / 16u) *(u32x4 *)(cidx + 16u * lane) = u32x4{0u, 0u, 0u, 0u};
+        uint32_t key = kRingNoRun, y = 0;
+        uint32_t start = 0;
+        uint32_t g = 0;
+        if (!alone) {
+            const bool valid = hp < kNotYet;  // a published header: the walk has read it, so it has landed
+            LaneRun run;
+            run.kind = kRle, run.count = 0, run.info = 0;
+            if (valid) run = decode_lane<1>(ring, hp & rmask, hp, end);
+            const uint32_t cnt = min(run.count, 2u * kRingBitsSpanValues);
+            start = hi + wave_inclusive_sum(cnt) - cnt;
+            bool ok = valid;
+            uint32_t value = run.info;
+            if (run.kind == kBitpacked) {
+                const uint32_t t = start < block_n ? min(run.count, block_n - start) : 0u;
+                ok = ok && run.info + ((t + 7u) >> 3) * w + 8u <= reach;
+                value = run.info * 8u - start * w;
+            }
+            const uint64_t bad = __ballot(!ok);  // lane 63 is never valid
+            g = (uint32_t)__builtin_ctzll(bad);
+            const uint32_t start_g = __builtin_amdgcn_readlane(start, g);
+            const uint32_t hp_g = __builtin_amdgcn_readlane(hp, g);
+            const bool ends = g < kLaneRuns && hp_g == kEndPos;  // no more runs: the rows behind are not the stream's
+            if (lane < g && start < block_n) {
+                key = (start << 1) | run.kind;
+                y = value;
+            }
+            if (ends && lane == g && start < block_n) key = (start << 1) | kRle;  // y stays 0: null rows
+            hi = (start_g >= block_n || ends) ? block_n : start_g;
+        }
+        tbl[(lane + 1u) & 63u] = lane == 63u ? make_uint2((lo << 1) | kind, y0) : make_uint2(key, y);
+        // ---- index: the run that holds the first row of every word -------------------------------------------
+        {
+            const uint32_t c = key != kRingNoRun ? (start + 31u) >> 5 : 0xffffffffu;
+            const uint32_t c_next = __builtin_amdgcn_update_dpp(0xffffffffu, c, 0x130, 0xf, 0xf, false);  // wave_shl:1
+            if (key != kRingNoRun && c != c_next) cidx[c] = (uint8_t)(lane + 1u);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (!alone) {  // lane l owns the words 2 l and 2 l + 1
+            const uint32_t d = *(const unsigned short *)&cidx[2u * lane];
+            uint32_t m0 = d & 0xffu, m1 = max(m0, d >> 8);
+            const uint32_t upto = wave_inclusive_max(m1);
+            const uint32_t before = __builtin_amdgcn_update_dpp(0u, upto, 0x138, 0xf, 0xf, false);  // wave_shr:1
+            m0 = max(m0, before), m1 = max(m1, before);
+            *(unsigned short *)&cidx[2u * lane] = (unsigned short)(m0 | (m1 << 8));
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        // ---- one word per lane and step -------------------------------------------------------------------------
+        const uint32_t wq0 = lo >> 5, wq_end = (hi + 31u) >> 5;
+        const bool hands_on = (hi & 31u) != 0u && hi < block_n;  // the pass ends inside a word that the next one completes
+        uint32_t carry_next = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 2u; ++i) {
+            if (wq0 + 64u * i >= wq_end) break;
+            const uint32_t q = wq0 + 64u * i + lane;
+            const bool active = q < wq_end;
+            uint32_t word = 0;
+            if (active) {
+                const uint32_t row0 = q * 32u;
+                uint32_t j = cidx[min(q, kRingBitsSpanWords)];
+                for (;;) {
+                    const uint2 e = tbl[j];
+                    const uint32_t nxt = tbl[j + 1u].x;
+                    const uint32_t r_end = min(nxt >> 1, hi);
+                    const uint32_t a = max(e.x >> 1, row0), b = min(r_end, row0 + 32u);
+                    if (a < b) {
+                        const uint32_t bits = (e.x & 1u) ? (e.y == 1u ? 0xffffffffu : 0u) : ring_bits32(ring, (e.y + row0) & bit_mask);
+                        const uint32_t m = (b - a == 32u) ? 0xffffffffu : (((1u << (b - a)) - 1u) << (a - row0));
+                        word |= bits & m;
+                    }
+                    if (r_end >= row0 + 32u || r_end >= hi) break;
+                    ++j;
+                }
+                if (q == wq0) word |= carry;
+            }
+            const uint32_t last_q = wq_end - 1u;
+            if (hands_on && last_q >= wq0 + 64u * i && last_q < wq0 + 64u * i + 64u)
+                carry_next = __builtin_amdgcn_readlane(word, __builtin_amdgcn_readfirstlane(last_q - wq0 - 64u * i));
+            if (active && !(hands_on && q == last_q)) {
+                words[q] = word;
+                set_bits += (uint32_t)__popc(word);
+            }
+        }
+        carry = carry_next;
+        // ---- next pass: run ridx + 1 + g becomes the first run -----------------------------------------------
+        if (hi < block_n && !alone) {
+            ridx += 1u + g;
+            const uint32_t have = io.await_runs(ridx - 1u, span_end, true, lane);
+            if (io.aborted) return;
+            (void)have;
+            const uint32_t at = __builtin_amdgcn_readfirstlane(io.sh.hq[ridx & (kHq - 1u)]);
+            io.raise_need(at, lane);
+            if (at != kEndPos) {
+                io.await_bytes(at + 32u, lane);
+                if (io.aborted) return;
+            }
+            auto rd = [&](uint32_t a) -> uint32_t {
+                return __builtin_amdgcn_readfirstlane(*(const uint32_t *)&ring[a & rmask]);
+            };
+            const RunInfo run = decode_run(rd, at, end, w, n - (span_start + hi));
+            if (run.kind >= kEnd || run.count == 0) {  // the closing entry: the stream is exhausted
+                kind = kRle, rem = kRemMask, payload = 0, skip = 0;
+            } else {
+                kind = run.kind, rem = run.count, skip = 0;
+                payload = run.kind == kRle ? run.value : run.payload;
+            }
+        }
+        if (hi < block_n && alone) {  // the first run continues
+            rem -= take0;
+            skip += take0;
+        }
+        lo = hi;
+    } while (lo < block_n);
+}
+
 // Selected rows: see tile_wanted in pq2_kernels.hip.
 __device__ __forceinline__ bool ring_tile_wanted(const PageDev &pg, const uint32_t *__restrict__ tile_mask, uint32_t t) {
     if (pg.reserved == 0u || tile_mask == nullptr) return true;
@@ -1255,13 +1447,17 @@ constexpr uint32_t kRingDictMaxBits = 12;  // widest index the kernels with a di
 
 // kWords = 0: the page's values are the decoded u32 (IndexSink).  kWords = 1, 2, 3: they are indices into the page's
 // dictionary of kWords-dword values, which the workgroup copies to LDS (from byte `dict_at` of its LDS on) before
-// it starts; `dicts` has a record per page, the statuses must be 0 at the launch.
+// it starts; `dicts` has a record per page, the statuses must be 0 at the launch.  kWords = -1: the pages hold
+// one-bit definition levels and come out as validity bitmaps (ring_expand_span_bits), page p's at the 4-byte aligned
+// address PageDev::out_addr; bit_meta[2 p] receives the rows the page's stream holds and bit_meta[2 p + 1], which
+// must be 0 at the launch, the number of set bits.
 template <bool kWide, int kWords>
 __global__ __launch_bounds__(kRingThreads, PQ2_RING_MIN_WAVES) void ring_kernel(const PageDev *__restrict__ pages, uint32_t n_pages,
                                                        int32_t *__restrict__ status, uint32_t *__restrict__ cu_tickets,
                                                        uint32_t ring_bytes, const uint32_t *__restrict__ tile_mask,
                                                        const RingDict *__restrict__ dicts, uint32_t dict_at,
-                                                       uint32_t whole_tile_spans, uint32_t epoch) {
+                                                       uint32_t whole_tile_spans, uint32_t epoch,
+                                                       uint32_t *__restrict__ bit_meta) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1271,7 +1467,8 @@ __global__ __launch_bounds__(kRingThreads, PQ2_RING_MIN_WAVES) void ring_kernel(
     const PageDev pg = pages[page];
     const uint32_t n = pg.num_values;
     if (n == 0) {
-        if (threadIdx.x == 0 && kWords == 0) status[page] = 0;
+        if (threadIdx.x == 0 && kWords <= 0) status[page] = 0;
+        if (threadIdx.x == 0 && kWords < 0) bit_meta[2u * page] = 0u;
         return;
     }
 #ifdef PQ2_RING_TRACE
@@ -1284,7 +1481,7 @@ __global__ __launch_bounds__(kRingThreads, PQ2_RING_MIN_WAVES) void ring_kernel(
     uint32_t *const dict_lds = (uint32_t *)(lds + dict_at);
     uint32_t dict_len = 0;
     uint64_t value_addr = 0;
-    if constexpr (kWords != 0) {
+    if constexpr (kWords > 0) {
         const RingDict dp = dicts[page];
         dict_len = dp.dict_len;
         value_addr = dp.out_addr;
@@ -1297,6 +1494,7 @@ __global__ __launch_bounds__(kRingThreads, PQ2_RING_MIN_WAVES) void ring_kernel(
     sh.hq = (uint32_t *)(lds + ring_bytes + kMirror);
     sh.rq = (Resume *)(lds + ring_bytes + kMirror + kHq * 4u);
     sh.ctl = (RingCtl *)(lds + ring_bytes + kMirror + kHq * 4u + kRq * 16u);
+    sh.rows_out = kWords < 0 ? bit_meta + 2u * page : nullptr;
     uint8_t *const tables = (uint8_t *)sh.ctl + sizeof(RingCtl);
     const uint32_t n_tiles = (n + kRingTileValues - 1u) / kRingTileValues;
     if (threadIdx.x < sizeof(RingCtl) / 4u) ((uint32_t *)sh.ctl)[threadIdx.x] = 0u;
@@ -1331,7 +1529,7 @@ __global__ __launch_bounds__(kRingThreads, PQ2_RING_MIN_WAVES) void ring_kernel(
     }
 
     if (wave == walker) {
-        ring_walk<kWide, kWords != 0>(pg, page, sh, status, lane);
+        ring_walk<kWide, (kWords > 0)>(pg, page, sh, status, lane);
         PQ2_TRACE_END(page);
         return;
     }
@@ -1347,8 +1545,9 @@ __global__ __launch_bounds__(kRingThreads, PQ2_RING_MIN_WAVES) void ring_kernel(
     io.status = status;
     io.page = page;
     io.aborted = false;
-    io.merge = kWords != 0;
+    io.merge = kWords > 0;
     bool bad_index = false;
+    uint32_t set_bits = 0;  // (bitmap mode) set bits in the words this lane has stored
 #ifdef PQ2_RING_TIMING
     for (int i = 0; i < 8; ++i) io.clocks[i] = 0;
     uint64_t *const clocks = io.clocks;
@@ -1370,7 +1569,8 @@ __global__ __launch_bounds__(kRingThreads, PQ2_RING_MIN_WAVES) void ring_kernel(
             // (`whole_tile_spans`: the launcher says so for batches of nothing but such pages; beside wider pages the
             // whole-tile spans cost more than they bring: configs[4]'s mix loses 2.6 % with them)
             const uint32_t span_blocks =
-                (kWords == 0 && kRingTileBlocks == 4 && whole_tile_spans != 0u && w != 0u && w <= kRingWholeTileBits) ? 4u : kRingSpanBlocks;
+                kWords < 0 ? kRingTileBlocks
+                : (kWords == 0 && kRingTileBlocks == 4 && whole_tile_spans != 0u && w != 0u && w <= kRingWholeTileBits) ? 4u : kRingSpanBlocks;
             const uint32_t span_values = span_blocks * kBlockValues;
             for (uint32_t i = 0; i < kRingTileBlocks / span_blocks; ++i) {
                 const uint32_t span_first = tile_first + i * span_values;
@@ -1398,7 +1598,15 @@ __global__ __launch_bounds__(kRingThreads, PQ2_RING_MIN_WAVES) void ring_kernel(
         else                                                                                                                \
             ring_expand_span<N, kRingSpanBlocks, kGroup>(io, tbl, cidx, rs, end, n, span_first, span_n, sink, lane);                \
         break;
-                if constexpr (kWords == 0) {
+                if constexpr (kWords < 0) {
+                    static_assert(kRingTileBlocks == 4, "a span of the bitmap mode is a tile of four blocks");
+                    uint32_t *const words = (uint32_t *)pg.out_addr + span_first / 32u;
+                    if (w == 1u) {
+                        ring_expand_span_bits(io, tbl, cidx, rs, end, n, span_first, span_n, words, set_bits, lane);
+                    } else {  // (the launcher sends pages of one bit; a page without a width has no rows)
+                        for (uint32_t q = lane; q < (span_n + 31u) / 32u; q += 64u) words[q] = 0u;
+                    }
+                } else if constexpr (kWords == 0) {
                     IndexSink sink = {out + i * span_values};
                     static_assert(kRingWholeTileBits <= 2, "the cases below");
                     switch (w) {
@@ -1457,7 +1665,11 @@ __global__ __launch_bounds__(kRingThreads, PQ2_RING_MIN_WAVES) void ring_kernel(
     io.tile = 0xffffffffu;  // through: the walk no longer counts on this wave
     io.need = kNoNeed;
     io.say(lane);
-    if (kWords != 0 && __ballot(bad_index) != 0 && lane == 0) atomicMax(&status[page], 1);  // PQ2_OUT_OF_SPEC
+    if (kWords > 0 && __ballot(bad_index) != 0 && lane == 0) atomicMax(&status[page], 1);  // PQ2_OUT_OF_SPEC
+    if constexpr (kWords < 0) {  // this wave's share of the page's set bits
+        const uint32_t total = wave_inclusive_sum(set_bits);
+        if (lane == 63u && total != 0u) atomicAdd(&bit_meta[2u * page + 1u], total);
+    }
     PQ2_CLOCK_ADD(8, clock_begin);
     PQ2_CLOCK_FLUSH(8);
     PQ2_TRACE_END(page);

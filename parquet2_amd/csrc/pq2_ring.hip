@@ -45,11 +45,29 @@ extern "C" hipError_t pq2_launch_ring(const void *pages, uint32_t n_pages, int32
         }
         hipLaunchKernelGGL((pq2::ring_kernel<true, 0>), dim3(n_pages), dim3(pq2::kRingThreads), lds_bytes, stream,
                            (const pq2::PageDev *)pages, n_pages, status, cu_tickets, ring_bytes, tile_mask,
-                           (const pq2::RingDict *)nullptr, 0u, whole_tile_spans, epoch);
+                           (const pq2::RingDict *)nullptr, 0u, whole_tile_spans, epoch, (uint32_t *)nullptr);
     } else {
         hipLaunchKernelGGL((pq2::ring_kernel<false, 0>), dim3(n_pages), dim3(pq2::kRingThreads), lds_bytes, stream,
                            (const pq2::PageDev *)pages, n_pages, status, cu_tickets, ring_bytes, tile_mask,
-                           (const pq2::RingDict *)nullptr, 0u, whole_tile_spans, epoch);
+                           (const pq2::RingDict *)nullptr, 0u, whole_tile_spans, epoch, (uint32_t *)nullptr);
     }
+    return hipGetLastError();
+}
+
+// ring_kernel for pages of one-bit definition levels that come out as validity bitmaps (ring_expand_span_bits).
+// `bit_meta`: two words per page, rows and set bits; the set bits must have been cleared on `stream`.
+extern "C" hipError_t pq2_launch_ring_bits(const void *pages, uint32_t n_pages, int32_t *status, uint32_t *cu_tickets,
+                                           uint32_t epoch, uint32_t *bit_meta, hipStream_t stream) {
+    if (n_pages == 0) return hipSuccess;
+    // Level streams are a few bytes per hundred rows and nothing is written per value: what a page takes is its walk,
+    // so the more walks a compute unit holds, the better.  A ring of 16 KiB lets six workgroups share its LDS.
+    uint32_t ring_bytes = 16384u;
+    if (const char *v = getenv("PQ2_RING_BYTES")) {  // tuning knob: 16384 or 32768
+        const uint32_t b = (uint32_t)atoi(v);
+        if (b == 16384u || b == 32768u) ring_bytes = b;
+    }
+    hipLaunchKernelGGL((pq2::ring_kernel<false, -1>), dim3(n_pages), dim3(pq2::kRingThreads), pq2::ring_lds_bytes(ring_bytes),
+                       stream, (const pq2::PageDev *)pages, n_pages, status, cu_tickets, ring_bytes,
+                       (const uint32_t *)nullptr, (const pq2::RingDict *)nullptr, 0u, 0u, epoch, bit_meta);
     return hipGetLastError();
 }

@@ -98,6 +98,13 @@ const char *pq2_ctx_last_schedule(const pq2_ctx *ctx);
  * pages of a pq2_multi_decode call count for the context that got them).  For tests and reports: which part of a
  * batch a context was given.  No counterpart in the reference. */
 uint64_t pq2_ctx_pages_total(const pq2_ctx *ctx);
+/* What the default schedule went by: the largest number of run headers it expected of a page of the last batch, if
+ * it looked at the streams before it chose (batches of 96 to 4096 pages that the descriptors send to ring_kernel:
+ * a wave per page walks the headers of the stream's first 500 bytes, and a batch whose pages would take their one
+ * walking wave longer than the scout kernels take for all of them goes to those); 0 if it did not look.  The
+ * environment variable PQ2_DENSITY_PROBE=0 turns the look off.  No counterpart in the reference
+ * (src/encoding/hybrid_rle/decoder.rs:30-64 is one decoder for every stream). */
+uint32_t pq2_ctx_last_density(const pq2_ctx *ctx);
 /* How the batches of this context are scheduled: "auto" (the default: the scout kernels for fewer than 96 pages, unless
  * every stream has at most 1 KiB, and
  * for up to 1024 pages that they are expected to get through before ring_kernel is done with its largest page,

@@ -66,6 +66,7 @@ SIGNATURES = {
     "pq2_ctx_enable_profiling": (C.c_int32, [C.c_void_p, C.c_int32]),
     "pq2_ctx_last_schedule": (C.c_char_p, [C.c_void_p]),
     "pq2_ctx_pages_total": (C.c_uint64, [C.c_void_p]),
+    "pq2_ctx_last_density": (C.c_uint32, [C.c_void_p]),
     "pq2_ctx_scout_rounds": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "pq2_ctx_set_schedule": (C.c_int32, [C.c_void_p, C.c_char_p]),
     "pq2_ctx_kernel_times": (C.c_int32, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), u64p, u64p]),

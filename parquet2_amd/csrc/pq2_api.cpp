@@ -47,7 +47,10 @@ hipError_t pq2_launch_bitunpack64(const void *d_packed, uint32_t packed_len, uin
 hipError_t pq2_launch_delta(const void *pages, uint32_t n_pages, void *results, hipStream_t stream);
 int32_t pq2_noalloc_setup(int32_t device, uint8_t **out);  // pq2_noalloc.hip
 hipError_t pq2_launch_ring(const void *pages, uint32_t n_pages, int32_t *status, uint32_t *cu_tickets, uint32_t epoch,
-                           uint32_t max_bits, const uint32_t *tile_mask, hipStream_t stream);  // pq2_ring.hip
+                           uint32_t max_bits, const uint32_t *tile_mask, const uint32_t *go, hipStream_t stream);  // pq2_ring.hip
+hipError_t pq2_launch_density(const void *pages, uint32_t n_pages, void *seen, float scout_us, float ring_fixed_us,
+                              float per_header_us, float values_us, float turns, uint32_t *go, uint32_t *host_words,
+                              uint32_t seq, hipStream_t stream);  // pq2_density.hip
 uint32_t pq2_ring_ticket_bytes();
 uint32_t pq2_ring_dict_max_bits();  // pq2_ring_dict.hip
 uint32_t pq2_ring_dict_max_bytes();
@@ -189,6 +192,14 @@ struct pq2_ctx {
     // pq2_decode_dict_batch_device: the decoded indices, and the per-page gather descriptors (page-locked + device)
     DevBuf d_indices, d_gather, d_seg_valid;
     DevBuf d_bit_meta;  // pq2_decode_validity_bitmap_batch_device: rows and set bits of every page
+    // density_kernel (pq2_density.hip): its two counters and the verdict word on the device, the verdict as the host
+    // reads it (page-locked, written by the device), the event behind the kernel, a count of its launches
+    DevBuf d_density;
+    uint32_t *h_density = nullptr;
+    hipEvent_t density_done = nullptr;
+    uint32_t density_seq = 0;
+    bool probe_density = true;  // PQ2_DENSITY_PROBE=0: the descriptors alone decide (A/B runs)
+    uint32_t last_density_headers = 0;  // largest estimated header count of a page, if the last batch was probed
     void *h_gather = nullptr;
     size_t h_gather_cap = 0;
     hipEvent_t gather_copied = nullptr;
@@ -324,15 +335,23 @@ bool takes_ring(const pq2_ctx *ctx, uint64_t n_pages) {
 // ring_kernel: 30 + the largest page at 0.57 per KB of stream or at 9.5 GB/s of values, whichever is more).  Pages of
 // very short runs take ring_kernel far longer than that, which only makes the choice of the scout kernels righter;
 // where such pages come in larger batches the caller has to say so (pq2_ctx_set_schedule).
-bool auto_takes_scout(const pq2_page_desc *descs, uint64_t n_pages) {
-    constexpr uint64_t kRingSlots = 1024;  // workgroups of ring_kernel that are resident at a time
-    if (n_pages > kRingSlots) return false;
+constexpr uint64_t kRingSlots = 1024;  // workgroups of ring_kernel that are resident at a time
+struct BatchBytes {
     double in_total = 0, out_total = 0, in_max = 0, out_max = 0;
+};
+BatchBytes batch_bytes(const pq2_page_desc *descs, uint64_t n_pages) {
+    BatchBytes b;
     for (uint64_t i = 0; i < n_pages; ++i) {
         const double in = double(descs[i].in_len), out = 4.0 * double(descs[i].num_values);
-        in_total += in, out_total += out;
-        in_max = std::max(in_max, in), out_max = std::max(out_max, out);
+        b.in_total += in, b.out_total += out;
+        b.in_max = std::max(b.in_max, in), b.out_max = std::max(b.out_max, out);
     }
+    return b;
+}
+bool auto_takes_scout(const pq2_page_desc *descs, uint64_t n_pages) {
+    if (n_pages > kRingSlots) return false;
+    const BatchBytes bb = batch_bytes(descs, n_pages);
+    const double in_total = bb.in_total, out_total = bb.out_total, in_max = bb.in_max, out_max = bb.out_max;
     if (n_pages < kScoutMaxPages) {
         // ... except where every stream is so short that one wave walks it, whatever it holds (a header every two
         // bytes, 0.06 us each), before the scout kernels' seven launches are through (70 us): 64 pages of 65 536
@@ -562,6 +581,43 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
         }
         return PQ2_OK;
     };
+    // The descriptors say ring_kernel -- but a page of short runs takes its one walking wave far longer than the
+    // scout kernels would take for the whole batch, and only the streams tell (pq2_density.hip).  In the range of
+    // batch sizes where that can turn the choice round, density_kernel looks at the first headers of every page and
+    // leaves its verdict in device memory; the ring_kernel launch goes out behind it at once and returns
+    // immediately if the verdict is "no", so that the usual case costs the few microseconds of the probe and no idle
+    // time; the host reads the verdict when the probe has run and, on a "no", enqueues the scout kernels instead.
+    uint32_t *d_go = nullptr;
+    ctx->last_density_headers = 0;
+    const bool probe = ring && !fused && !bits && !front && !mask && ctx->mode == pq2_ctx::kAuto && ctx->probe_density &&
+                       n_pages >= kScoutMaxPages && n_pages <= 4 * kRingSlots;
+    if (probe) {
+        // (device: the verdict word, then two words per sampled page of what the pages showed)
+        if ((st = reserve(ctx, ctx->d_density, 16 + 512 * 8))) return st;
+        if (!ctx->h_density) {
+            PQ2_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_density), 64, hipHostMallocMapped));
+            ctx->h_density[0] = ctx->h_density[1] = 0;
+            PQ2_HIP(ctx, hipEventCreateWithFlags(&ctx->density_done, hipEventDisableTiming));
+        }
+        uint32_t *d_host_words = nullptr;
+        PQ2_HIP(ctx, hipHostGetDevicePointer(reinterpret_cast<void **>(&d_host_words), ctx->h_density, 0));
+        d_go = static_cast<uint32_t *>(ctx->d_density.ptr);
+        void *const d_seen = d_go + 4;
+        const BatchBytes bb = batch_bytes(descs, n_pages);
+        // (microseconds, as in auto_takes_scout; a header costs a walking wave 0.1 us, and up to twice that where four
+        // walks of dense headers share a compute unit)
+        const double scout_us = 40.0 + bb.in_total * 2.8e-6 + bb.out_total / 3.5e6;
+        const double turns = double((n_pages + kRingSlots - 1) / kRingSlots);
+        const double per_header_us = n_pages <= kRingSlots / 4 ? 0.1 : 0.16;
+        ++ctx->density_seq;
+        if ((st = stamped(false, stream, [&] {
+                 return pq2_launch_density(d_pages, static_cast<uint32_t>(n_pages), d_seen, float(scout_us), 30.0f,
+                                           float(per_header_us), float(bb.out_max / 9.5e3), float(turns), d_go,
+                                           d_host_words, ctx->density_seq & 0x7fffffffu, stream);
+             })))
+            return st;
+        PQ2_HIP(ctx, hipEventRecord(ctx->density_done, stream));
+    }
     if (per_page) {
         if (!ctx->d_tickets.ptr) {
             const size_t ticket_bytes = pq2_cu_ticket_bytes() + pq2_ring_ticket_bytes();
@@ -583,13 +639,32 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
                                                  ctx->ring_epoch++, bits->d_meta, stream);
                  if (ring)
                      return pq2_launch_ring(d_pages, static_cast<uint32_t>(n_pages), d_status, ring_tickets,
-                                            ctx->ring_epoch++, max_bits, d_tile_mask, stream);
+                                            ctx->ring_epoch++, max_bits, d_tile_mask, d_go, stream);
                  return pq2_launch_decode(d_pages, static_cast<uint32_t>(n_pages), ctx->d_resume.ptr, d_run_pos, d_status,
                                           ctx->d_state.ptr, static_cast<uint32_t *>(ctx->d_tickets.ptr), max_bits,
                                           d_tile_mask, stream);
              })))
             return st;
         rounds = 0;
+    }
+    if (probe) {
+        PQ2_HIP(ctx, hipEventSynchronize(ctx->density_done));
+        const uint32_t word = reinterpret_cast<volatile uint32_t *>(ctx->h_density)[0];
+        ctx->last_density_headers = reinterpret_cast<volatile uint32_t *>(ctx->h_density)[1];
+        if ((word >> 1) != (ctx->density_seq & 0x7fffffffu)) return fail(ctx, PQ2_DEVICE_ERROR, "the density probe left no verdict");
+        if ((word & 1u) == 0u) {
+            // the ring_kernel launch above finds the same verdict and touches nothing: the scout kernels take the batch
+            // (what was stamped for it counts as time of the header walk)
+            if (ctx->profiling && !ctx->stamps.empty()) ctx->stamps.back().expand = false;
+            const pq2_ctx::Mode was = ctx->mode;
+            const uint32_t expected = ctx->last_density_headers;
+            ctx->mode = pq2_ctx::kScout;
+            st = enqueue_batch(ctx, d_in, in_bytes, descs, n_pages, d_out, out_values, stream, front, min_max_bits, mask,
+                               fused, bits);
+            ctx->mode = was;
+            ctx->last_density_headers = expected;
+            return st;
+        }
     }
     if (scout) {
         if ((st = stamped(false, stream, [&] {
@@ -670,6 +745,7 @@ int32_t pq2_ctx_create(int32_t device_id, pq2_ctx **out) {
     }
     if (const char *v = std::getenv("PQ2_EXPAND_STREAMS")) ctx->one_expand_stream = std::atoi(v) != 2;
     if (const char *v = std::getenv("PQ2_MODE")) (void)pq2_ctx_set_schedule(ctx, v);  // another word: as without
+    if (const char *v = std::getenv("PQ2_DENSITY_PROBE")) ctx->probe_density = std::atoi(v) != 0;
     if (const char *v = std::getenv("PQ2_ROUND_SPLIT")) {
         double a = 0, b = 0, c = 0;
         if (std::sscanf(v, "%lf,%lf,%lf", &a, &b, &c) == 3 && 0 <= a && a <= b && b <= c && c <= 1)
@@ -707,7 +783,7 @@ int32_t pq2_ctx_destroy(pq2_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     for (DevBuf *b : {&ctx->d_meta, &ctx->d_status, &ctx->d_resume, &ctx->d_tile_page, &ctx->d_run_pos, &ctx->d_state,
-                      &ctx->d_tickets, &ctx->d_scout_table, &ctx->d_scout_words, &ctx->d_seg_valid, &ctx->d_bit_meta, &ctx->d_indices, &ctx->d_gather, &ctx->d_in, &ctx->d_out})
+                      &ctx->d_tickets, &ctx->d_scout_table, &ctx->d_scout_words, &ctx->d_seg_valid, &ctx->d_bit_meta, &ctx->d_density, &ctx->d_indices, &ctx->d_gather, &ctx->d_in, &ctx->d_out})
         if (b->ptr) (void)hipFree(b->ptr);
     for (hipStream_t s : {ctx->parse_stream, ctx->expand_stream[0], ctx->expand_stream[1]})
         if (s) (void)hipStreamDestroy(s);
@@ -716,6 +792,8 @@ int32_t pq2_ctx_destroy(pq2_ctx *ctx) {
         if (e) (void)hipEventDestroy(e);
     if (ctx->h_meta) (void)hipHostFree(ctx->h_meta);
     if (ctx->h_gather) (void)hipHostFree(ctx->h_gather);
+    if (ctx->h_density) (void)hipHostFree(ctx->h_density);
+    if (ctx->density_done) (void)hipEventDestroy(ctx->density_done);
     if (ctx->gather_copied) (void)hipEventDestroy(ctx->gather_copied);
     if (ctx->meta_copied) (void)hipEventDestroy(ctx->meta_copied);
     for (auto &s : ctx->stamps) {
@@ -748,6 +826,8 @@ const char *pq2_last_error(const pq2_ctx *ctx) { return ctx ? ctx->last_error.c_
 const char *pq2_ctx_last_schedule(const pq2_ctx *ctx) { return ctx ? ctx->last_schedule : ""; }
 
 uint64_t pq2_ctx_pages_total(const pq2_ctx *ctx) { return ctx ? ctx->pages_total : 0; }
+
+uint32_t pq2_ctx_last_density(const pq2_ctx *ctx) { return ctx ? ctx->last_density_headers : 0; }
 
 int32_t pq2_ctx_scout_rounds(pq2_ctx *ctx, uint32_t *rounds, uint64_t n_pages) {
     if (!ctx || (!rounds && n_pages)) return PQ2_INVALID_PARAMETER;

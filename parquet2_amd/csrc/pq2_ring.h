@@ -1457,8 +1457,11 @@ __global__ __launch_bounds__(kRingThreads, PQ2_RING_MIN_WAVES) void ring_kernel(
                                                        uint32_t ring_bytes, const uint32_t *__restrict__ tile_mask,
                                                        const RingDict *__restrict__ dicts, uint32_t dict_at,
                                                        uint32_t whole_tile_spans, uint32_t epoch,
-                                                       uint32_t *__restrict__ bit_meta) {
+                                                       uint32_t *__restrict__ bit_meta, const uint32_t *__restrict__ go) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    // a launch that was enqueued before the batch's schedule was final (density_kernel, pq2_density.hip) and has
+    // been told that the other schedule takes the batch: nothing is touched
+    if (go != nullptr && *go == 0u) return;
 
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;

@@ -25,8 +25,10 @@ extern "C" uint32_t pq2_ring_ticket_bytes() { return pq2::kRingCuTickets * 4u; }
 // width 32) leaves room for two workgroups per compute unit instead of four and is 13-17 % slower at every such
 // width.  `max_bits`: the largest width of a page of the batch.
 // `epoch`: a count of the launches that use `cu_tickets` (see ring_pick_walker).
+// `go`: null, or a word of device memory that says, by the time the kernel runs, whether it is to run at all.
 extern "C" hipError_t pq2_launch_ring(const void *pages, uint32_t n_pages, int32_t *status, uint32_t *cu_tickets,
-                                      uint32_t epoch, uint32_t max_bits, const uint32_t *tile_mask, hipStream_t stream) {
+                                      uint32_t epoch, uint32_t max_bits, const uint32_t *tile_mask, const uint32_t *go,
+                                      hipStream_t stream) {
     if (n_pages == 0) return hipSuccess;
     uint32_t ring_bytes = 32768u;
     if (const char *v = getenv("PQ2_RING_BYTES")) {  // tuning knob: 16384, 32768 or 65536
@@ -45,11 +47,11 @@ extern "C" hipError_t pq2_launch_ring(const void *pages, uint32_t n_pages, int32
         }
         hipLaunchKernelGGL((pq2::ring_kernel<true, 0>), dim3(n_pages), dim3(pq2::kRingThreads), lds_bytes, stream,
                            (const pq2::PageDev *)pages, n_pages, status, cu_tickets, ring_bytes, tile_mask,
-                           (const pq2::RingDict *)nullptr, 0u, whole_tile_spans, epoch, (uint32_t *)nullptr);
+                           (const pq2::RingDict *)nullptr, 0u, whole_tile_spans, epoch, (uint32_t *)nullptr, go);
     } else {
         hipLaunchKernelGGL((pq2::ring_kernel<false, 0>), dim3(n_pages), dim3(pq2::kRingThreads), lds_bytes, stream,
                            (const pq2::PageDev *)pages, n_pages, status, cu_tickets, ring_bytes, tile_mask,
-                           (const pq2::RingDict *)nullptr, 0u, whole_tile_spans, epoch, (uint32_t *)nullptr);
+                           (const pq2::RingDict *)nullptr, 0u, whole_tile_spans, epoch, (uint32_t *)nullptr, go);
     }
     return hipGetLastError();
 }
@@ -68,6 +70,6 @@ extern "C" hipError_t pq2_launch_ring_bits(const void *pages, uint32_t n_pages, 
     }
     hipLaunchKernelGGL((pq2::ring_kernel<false, -1>), dim3(n_pages), dim3(pq2::kRingThreads), pq2::ring_lds_bytes(ring_bytes),
                        stream, (const pq2::PageDev *)pages, n_pages, status, cu_tickets, ring_bytes,
-                       (const uint32_t *)nullptr, (const pq2::RingDict *)nullptr, 0u, 0u, epoch, bit_meta);
+                       (const uint32_t *)nullptr, (const pq2::RingDict *)nullptr, 0u, 0u, epoch, bit_meta, (const uint32_t *)nullptr);
     return hipGetLastError();
 }

@@ -39,7 +39,7 @@ extern "C" hipError_t pq2_launch_ring_dict(const void *pages, uint32_t n_pages, 
     }                                                                                                                 \
     hipLaunchKernelGGL((pq2::ring_kernel<false, WORDS>), dim3(n_pages), dim3(pq2::kRingThreads), lds_bytes, stream,   \
                        (const pq2::PageDev *)pages, n_pages, status, cu_tickets, ring_bytes, tile_mask,               \
-                       (const pq2::RingDict *)dicts, dict_at, 0u, epoch, (uint32_t *)nullptr)
+                       (const pq2::RingDict *)dicts, dict_at, 0u, epoch, (uint32_t *)nullptr, (const uint32_t *)nullptr)
     if (value_words == 1u) {
         PQ2_LAUNCH(1);
     } else if (value_words == 2u) {

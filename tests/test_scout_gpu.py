@@ -408,3 +408,65 @@ def test_schedule_follows_the_batch(oracle):
                 assert st_o == OK and (got[o:o + n] == exp).all(), (len(pages), k)
     finally:
         ctx.close()
+
+
+def test_schedule_follows_the_headers(oracle):
+    """Batches that the descriptors send to ring_kernel are looked at first (density_kernel: the headers of every
+    stream's first 500 bytes): pages of short runs, which would each take their one walking wave far longer than
+    the scout kernels take for all of them, go to the scout kernels whatever their number; pages of long runs stay;
+    one page of short runs among pages of long ones is enough.  The estimate of the largest header count of a page
+    is within a factor of two of the truth.  Values as the oracle's either way."""
+    import torch
+
+    from parquet2_amd import Context
+    from parquet2_amd._lib import lib
+
+    n = 1 << 18
+    short, _ = synth.adversarial(synth.seed_for(4, 1), n, 17)
+    long_, _ = synth.dict_page(synth.seed_for(2, 3), n, 12)
+    levels, _ = synth.def_levels_page(synth.seed_for(3, 2), n)
+
+    def headers_of(stream, w):
+        st, runs = oracle.runs(bytes(stream), w)
+        return len(runs)
+
+    ctx = Context(0)
+    try:
+        for pages, want, truth in (([(short, 17, n)] * 256, "scout+expand_kernel", headers_of(short, 17)),
+                                   ([(short, 17, n)] * 1500, "scout+expand_kernel", headers_of(short, 17)),
+                                   ([(long_, 12, n)] * 256, "ring_kernel", headers_of(long_, 12)),
+                                   ([(long_, 12, n)] * 1500, "ring_kernel", headers_of(long_, 12)),
+                                   ([(long_, 12, n)] * 200 + [(short, 17, n)] + [(long_, 12, n)] * 99, "scout+expand_kernel",
+                                    headers_of(short, 17)),
+                                   ([(long_, 12, n), (long_, 12, n), (long_, 12, n), (levels, 1, n)] * 80, "ring_kernel",
+                                    max(headers_of(long_, 12), headers_of(levels, 1)))):
+            batch = synth.PageBatch()
+            for stream, w, k in pages:
+                batch.add(stream, w, k)
+            data, descs, out_values = batch.finish()
+            d_in = torch.from_numpy(data).cuda()
+            d_out = torch.full((out_values,), -1, dtype=torch.int32, device="cuda")
+            st = ctx.decode_batch_device(d_in.data_ptr(), d_in.numel(), descs, d_out.data_ptr(), out_values,
+                                         torch.cuda.current_stream().cuda_stream)
+            assert (st == OK).all()
+            expected = lib().pq2_ctx_last_density(ctx._h)
+            assert ctx.last_schedule() == want, (len(pages), ctx.last_schedule(), expected, truth)
+            assert truth / 2 <= expected <= truth * 2, (len(pages), expected, truth)
+            got = d_out.cpu().numpy().view(np.uint32)
+            for k in (0, 200, len(pages) - 1):
+                stream, w, cnt = pages[k]
+                st_o, exp = oracle.hybrid_rle_decode(stream, w, cnt)
+                o = int(descs[k]["out_off"])
+                assert st_o == OK and (got[o:o + cnt] == exp).all(), (len(pages), k)
+        # a context that is told its schedule, and batches outside the range, are not looked at
+        ctx.set_schedule("ring")
+        batch = synth.PageBatch()
+        for _ in range(256):
+            batch.add(long_, 12, n)
+        data, descs, out_values = batch.finish()
+        d_in = torch.from_numpy(data).cuda()
+        d_out = torch.zeros(out_values, dtype=torch.int32, device="cuda")
+        ctx.decode_batch_device(d_in.data_ptr(), d_in.numel(), descs, d_out.data_ptr(), out_values, 0)
+        assert lib().pq2_ctx_last_density(ctx._h) == 0 and ctx.last_schedule() == "ring_kernel"
+    finally:
+        ctx.close()

@@ -24,6 +24,27 @@ def test_pq2hip_exports_every_declared_symbol():
     assert sorted(_lib.SIGNATURES) == names
 
 
+def test_rust_sys_crate_declares_every_export():
+    """rust/pq2hip-sys/src/lib.rs (sources only: no rustc here) has an extern "C" item for every export of the
+    header, with as many parameters, and nothing the header does not have."""
+    header = open(os.path.join(ROOT, "include", "pq2hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    want = {name: 0 if args.strip() in ("", "void") else args.count(",") + 1
+            for name, args in re.findall(r"\b(pq2_\w+)\s*\(([^;{]*?)\)\s*;", header, flags=re.S)}
+    rust = open(os.path.join(ROOT, "rust", "pq2hip-sys", "src", "lib.rs")).read()
+    rust = re.sub(r"//[^\n]*", "", rust)
+    have = {name: 0 if not args.strip() else args.count(":")
+            for name, args in re.findall(r"pub fn (pq2_\w+)\s*\(([^;]*?)\)\s*(?:->[^;]*)?;", rust, flags=re.S)}
+    assert sorted(have) == sorted(want)
+    assert have == want
+    # the structs of the header, field for field
+    for struct, fields in re.findall(r"typedef struct (pq2_\w+) \{(.*?)\}", header, flags=re.S):
+        names = [n for decl in fields.split(";") for n in re.findall(r"(\w+)\s*(?:,|$)", decl.strip())]
+        body = re.search(r"pub struct %s \{(.*?)\}" % struct, rust, flags=re.S)
+        assert body, struct
+        assert re.findall(r"pub (\w+):", body.group(1)) == names, struct
+
+
 def test_pq2synth_exports_every_declared_symbol():
     from parquet2_amd import synth
 

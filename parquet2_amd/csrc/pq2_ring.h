@@ -1398,6 +1398,220 @@ __device__ __forceinline__ void ring_expand_span_bits(RingExpander &io, uint2 *t
     } while (lo < block_n);
 }
 
+// One wave decodes the span [span_start, span_start + block_n) of a page of one-bit levels into u32 values: the
+// decode of HybridRleDecoder at width 1 (definition and repetition levels of flat columns), by way of the span's bits.
+// ring_expand_span spends some twenty-five instructions on every 256 values whatever the width; at width 1 a pass
+// can assemble its rows 32 to a word first (as ring_expand_span_bits does: a lane ORs together the parts of the runs
+// that overlap its word) and then spread the words' bits over the output, four values per lane and step -- a
+// third of the instructions, and pages of levels are bound by them.  An RLE run whose value is not 0 or 1 (the value
+// byte is not masked to the width, mod.rs:51-55) has no bit to stand for it: a pass that holds one writes its runs
+// one after the other instead.
+template <uint32_t kSpanBlocks>
+__device__ __forceinline__ void ring_expand_span_levels(RingExpander &io, uint2 *tbl, void *cidx_lds, const Resume rs,
+                                                        const uint32_t end, const uint32_t n, const uint32_t span_start,
+                                                        const uint32_t block_n, IndexSink &sink, const uint32_t lane) {
+    constexpr uint32_t kSpanValues = kSpanBlocks * kBlockValues;
+    constexpr uint32_t kSpanWords = kSpanValues / 32u;
+    static_assert(kSpanWords + 16u + 16u + (kSpanWords + 4u) * 4u <= RingSpan<2>::kBytes, "index and words fit the chunk index's LDS");
+    uint32_t *const wbuf = (uint32_t *)((uint8_t *)cidx_lds + ((kSpanWords + 16u + 15u) & ~15u));  // kSpanWords + 4 words
+    const uint32_t mis = sink.mis();
+    constexpr uint32_t w = 1u;
+    constexpr uint32_t kLaneRuns = kRingTableRuns - 1;
+    uint8_t *const cidx = (uint8_t *)cidx_lds;
+    const uint8_t *const ring = io.sh.ring;
+    const uint32_t rmask = io.sh.ring_bytes - 1u;
+    const uint32_t bit_mask = io.sh.ring_bytes * 8u - 1u;
+    const uint32_t max_vals = ((io.cap - 256u) / w) * 8u;  // values of one run the ring surely holds at once
+    const uint32_t span_end = span_start + block_n;
+
+    uint32_t kind = rs.rem_kind >> 31;
+    uint32_t rem = rs.rem_kind & kRemMask;
+    uint32_t payload = rs.payload;  // RLE: the value
+    uint32_t skip = rs.skip;        // bit-packed only
+    uint32_t ridx = rs.run_index;
+    uint32_t lo = 0;
+    // the span's bits, 0 until a pass puts its rows in
+    for (uint32_t i = lane; i < kSpanWords + 4u; i += 64u) wbuf[i] = 0u;
+
+    do {
+        // ---- the runs that cover [lo, hi) into the table (as ring_expand_span's phase 1) ---------------------
+        uint32_t take0 = min(rem, block_n - lo);
+        uint32_t y0 = payload;
+        bool alone = take0 == block_n - lo;
+        uint32_t from = kEndPos;  // the first stream byte this pass reads
+        if (kind == kBitpacked) {
+            const uint32_t b_lo = payload + (skip >> 3) * w;
+            if (take0 > max_vals) take0 = max_vals, alone = true;
+            from = b_lo;
+            y0 = b_lo * 8u + (skip & 7u) * w - lo * w;  // ring bit position of the span's row 0 (taken mod 8R)
+        }
+        uint32_t runs = 0;
+        if (!alone) {
+            runs = io.await_runs(ridx, span_end, false, lane);
+            if (io.aborted) return;
+        }
+        uint32_t hi = lo + take0;
+        uint32_t hp = kNotYet;
+        if (!alone && lane < kLaneRuns && ridx + 1u + lane < runs) hp = io.sh.hq[(ridx + 1u + lane) & (kHq - 1u)];
+        const uint32_t hp0 = __builtin_amdgcn_readfirstlane(hp);
+        if (kind == kRle && hp0 < kNotYet) from = hp0;
+        uint32_t avail = lds_load(&io.sh.ctl->landed);
+        if (from != kEndPos) {
+            io.raise_need(from, lane);
+            const uint32_t first_end = payload + ((skip + take0 + 7u) >> 3) * w + 8u;
+            if (kind == kBitpacked && avail < min(first_end, lds_load(&io.sh.ctl->final_hi))) {
+                io.await_bytes(first_end, lane);
+                if (io.aborted) return;
+                avail = lds_load(&io.sh.ctl->landed);
+            }
+        }
+        const uint32_t reach = io.need >= kNoNeed ? avail : min(avail, io.need + io.cap);  // bytes this pass may read
+
+        if (lane < (kSpanWords + 16u + 15u) / 16u) *(u32x4 *)(cidx + 16u * lane) = u32x4{0u, 0u, 0u, 0u};
+        uint32_t key = kRingNoRun, y = 0;
+        uint32_t start = 0;
+        uint32_t g = 0;
+        if (!alone) {
+            const bool valid = hp < kNotYet;  // a published header: the walk has read it, so it has landed
+            LaneRun run;
+            run.kind = kRle, run.count = 0, run.info = 0;
+            if (valid) run = decode_lane<1>(ring, hp & rmask, hp, end);
+            const uint32_t cnt = min(run.count, 2u * kSpanValues);
+            start = hi + wave_inclusive_sum(cnt) - cnt;
+            bool ok = valid;
+            uint32_t value = run.info;
+            if (run.kind == kBitpacked) {
+                const uint32_t t = start < block_n ? min(run.count, block_n - start) : 0u;
+                ok = ok && run.info + ((t + 7u) >> 3) * w + 8u <= reach;
+                value = run.info * 8u - start * w;
+            }
+            const uint64_t bad = __ballot(!ok);  // lane 63 is never valid
+            g = (uint32_t)__builtin_ctzll(bad);
+            const uint32_t start_g = __builtin_amdgcn_readlane(start, g);
+            const uint32_t hp_g = __builtin_amdgcn_readlane(hp, g);
+            const bool ends = g < kLaneRuns && hp_g == kEndPos;  // no more runs: the rows behind are not the stream's
+            if (lane < g && start < block_n) {
+                key = (start << 1) | run.kind;
+                y = value;
+            }
+            if (ends && lane == g && start < block_n) key = (start << 1) | kRle;  // y stays 0: null rows
+            hi = (start_g >= block_n || ends) ? block_n : start_g;
+        }
+        tbl[(lane + 1u) & 63u] = lane == 63u ? make_uint2((lo << 1) | kind, y0) : make_uint2(key, y);
+        // ---- index: the run that holds the first row of every word -------------------------------------------
+        {
+            const uint32_t c = key != kRingNoRun ? (start + 31u) >> 5 : 0xffffffffu;
+            const uint32_t c_next = __builtin_amdgcn_update_dpp(0xffffffffu, c, 0x130, 0xf, 0xf, false);  // wave_shl:1
+            if (key != kRingNoRun && c != c_next) cidx[c] = (uint8_t)(lane + 1u);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (!alone) {
+            if constexpr (kSpanWords == 128u) {  // lane l owns the words 2 l and 2 l + 1
+                const uint32_t d = *(const unsigned short *)&cidx[2u * lane];
+                uint32_t m0 = d & 0xffu, m1 = max(m0, d >> 8);
+                const uint32_t upto = wave_inclusive_max(m1);
+                const uint32_t before = __builtin_amdgcn_update_dpp(0u, upto, 0x138, 0xf, 0xf, false);  // wave_shr:1
+                m0 = max(m0, before), m1 = max(m1, before);
+                *(unsigned short *)&cidx[2u * lane] = (unsigned short)(m0 | (m1 << 8));
+            } else {  // lane l owns word l
+                static_assert(kSpanWords == 64u || kSpanWords == 128u, "spans of 2 or 4 blocks");
+                cidx[lane] = (uint8_t)wave_inclusive_max((uint32_t)cidx[lane]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        // an RLE run of this pass whose value no bit stands for?
+        const bool wide = __ballot(key != kRingNoRun && (key & 1u) != 0u && y > 1u) != 0ull || (kind == kRle && y0 > 1u);
+        if (__builtin_expect(!wide, 1)) {
+            // ---- the pass's rows into the span's bits: one word per lane and step -----------------------------
+            const uint32_t wq0 = lo >> 5, wq_end = (hi + 31u) >> 5;
+#pragma unroll
+            for (uint32_t i = 0; i < kSpanWords / 64u; ++i) {
+                if (wq0 + 64u * i >= wq_end) break;
+                const uint32_t q = wq0 + 64u * i + lane;
+                if (q < wq_end) {
+                    const uint32_t row0 = q * 32u;
+                    uint32_t word = 0;
+                    uint32_t j = cidx[min(q, kSpanWords)];
+                    for (;;) {
+                        const uint2 e = tbl[j];
+                        const uint32_t nxt = tbl[j + 1u].x;
+                        const uint32_t r_end = min(nxt >> 1, hi);
+                        const uint32_t a = max(e.x >> 1, row0), b = min(r_end, row0 + 32u);
+                        if (a < b) {
+                            const uint32_t bits = (e.x & 1u) ? (e.y == 1u ? 0xffffffffu : 0u) : ring_bits32(ring, (e.y + row0) & bit_mask);
+                            const uint32_t m = (b - a == 32u) ? 0xffffffffu : (((1u << (b - a)) - 1u) << (a - row0));
+                            word |= bits & m;
+                        }
+                        if (r_end >= row0 + 32u || r_end >= hi) break;
+                        ++j;
+                    }
+                    wbuf[q] |= word;  // (the word that holds row `lo` has the bits of the pass before)
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // ---- the bits of rows [lo, hi) as values: one 16-byte chunk per lane and step ---------------------
+            const uint32_t q_end = (hi + mis + 3u) >> 2;
+            for (uint32_t q = ((lo + mis) >> 2) + lane; q < q_end; q += 64u) {
+                const int32_t p = (int32_t)(q * 4u) - (int32_t)mis;  // the chunk's first row
+                if (p >= (int32_t)lo && p + 4 <= (int32_t)hi) {
+                    const uint32_t wi = (uint32_t)p >> 5;
+                    const uint32_t nib = __builtin_amdgcn_alignbit(wbuf[wi + 1u], wbuf[wi], (uint32_t)p & 31u);
+                    sink.put4(u32x4{nib & 1u, (nib >> 1) & 1u, (nib >> 2) & 1u, (nib >> 3) & 1u}, p);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int32_t r = p + k;
+                        if (r >= (int32_t)lo && r < (int32_t)hi) sink.put1((wbuf[(uint32_t)r >> 5] >> ((uint32_t)r & 31u)) & 1u, r);
+                    }
+                }
+            }
+        } else {
+            // ---- run after run, a value per lane and step (streams no writer produces) -----------------------------
+            for (uint32_t j = 0;; ++j) {
+                const uint2 e = tbl[j];
+                const uint32_t nxt = tbl[j + 1u].x;
+                const uint32_t r_end = min(nxt >> 1, hi);
+                for (uint32_t r = (e.x >> 1) + lane; r < r_end; r += 64u) {
+                    const uint32_t bit = (ring[(((e.y + r) & bit_mask) >> 3)] >> ((e.y + r) & 7u)) & 1u;
+                    sink.put1((e.x & 1u) ? e.y : bit, (int32_t)r);
+                }
+                if (r_end >= hi || j + 1u > kRingTableRuns) break;
+            }
+        }
+        // ---- next pass: run ridx + 1 + g becomes the first run -----------------------------------------------
+        if (hi < block_n && !alone) {
+            ridx += 1u + g;
+            const uint32_t have = io.await_runs(ridx - 1u, span_end, true, lane);
+            if (io.aborted) return;
+            (void)have;
+            const uint32_t at = __builtin_amdgcn_readfirstlane(io.sh.hq[ridx & (kHq - 1u)]);
+            io.raise_need(at, lane);
+            if (at != kEndPos) {
+                io.await_bytes(at + 32u, lane);
+                if (io.aborted) return;
+            }
+            auto rd = [&](uint32_t a) -> uint32_t {
+                return __builtin_amdgcn_readfirstlane(*(const uint32_t *)&ring[a & rmask]);
+            };
+            const RunInfo run = decode_run(rd, at, end, w, n - (span_start + hi));
+            if (run.kind >= kEnd || run.count == 0) {  // the closing entry: the stream is exhausted
+                kind = kRle, rem = kRemMask, payload = 0, skip = 0;
+            } else {
+                kind = run.kind, rem = run.count, skip = 0;
+                payload = run.kind == kRle ? run.value : run.payload;
+            }
+        }
+        if (hi < block_n && alone) {  // the first run continues
+            rem -= take0;
+            skip += take0;
+        }
+        lo = hi;
+    } while (lo < block_n);
+}
+
 // Selected rows: see tile_wanted in pq2_kernels.hip.
 __device__ __forceinline__ bool ring_tile_wanted(const PageDev &pg, const uint32_t *__restrict__ tile_mask, uint32_t t) {
     if (pg.reserved == 0u || tile_mask == nullptr) return true;
@@ -1594,6 +1808,13 @@ __global__ __launch_bounds__(kRingThreads, PQ2_RING_MIN_WAVES) void ring_kernel(
     case N:                                                                                                 \
         ring_expand_span<N, kRingSpanBlocks, kGroup>(io, tbl, cidx, rs, end, n, span_first, span_n, sink, lane);    \
         break;
+#define PQ2_W_BITS                                                                                               \
+    case 1:                                                                                                          \
+        if (span_blocks == 4u)                                                                                       \
+            ring_expand_span_levels<kRingTileBlocks == 4 ? 4 : 2>(io, tbl, cidx, rs, end, n, span_first, span_n, sink, lane); \
+        else                                                                                                         \
+            ring_expand_span_levels<kRingSpanBlocks>(io, tbl, cidx, rs, end, n, span_first, span_n, sink, lane);      \
+        break;
 #define PQ2_W_LEVELS(N)                                                                                                     \
     case N:                                                                                                                 \
         if (span_blocks == 4u)                                                                                              \
@@ -1616,7 +1837,7 @@ __global__ __launch_bounds__(kRingThreads, PQ2_RING_MIN_WAVES) void ring_kernel(
 #ifdef PQ2_ONLY_W
                         PQ2_W(PQ2_ONLY_W)
 #else
-                        PQ2_W_LEVELS(1) PQ2_W_LEVELS(2) PQ2_W(3) PQ2_W(4) PQ2_W(5) PQ2_W(6) PQ2_W(7) PQ2_W(8)
+                        PQ2_W_BITS PQ2_W_LEVELS(2) PQ2_W(3) PQ2_W(4) PQ2_W(5) PQ2_W(6) PQ2_W(7) PQ2_W(8)
                         PQ2_W(9) PQ2_W(10) PQ2_W(11) PQ2_W(12) PQ2_W(13) PQ2_W(14) PQ2_W(15) PQ2_W(16)
 #endif
                         default:
@@ -1656,6 +1877,7 @@ __global__ __launch_bounds__(kRingThreads, PQ2_RING_MIN_WAVES) void ring_kernel(
                     bad_index |= sink.bad;
                 }
 #undef PQ2_W
+#undef PQ2_W_BITS
 #undef PQ2_W_LEVELS
                 if (io.aborted) return;
             }

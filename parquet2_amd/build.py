@@ -12,7 +12,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 OBJ_DIR = os.path.join(LIB_DIR, "obj")
 LIB = os.path.join(LIB_DIR, "libpq2hip.so")
-SOURCES = ["pq2_kernels.hip", "pq2_ring.hip", "pq2_ring_dict.hip", "pq2_scout.hip", "pq2_density.hip", "pq2_noalloc.hip", "pq2_api.cpp", "pq2_host.cpp"]
+SOURCES = ["pq2_kernels.hip", "pq2_ring.hip", "pq2_ring_dict.hip", "pq2_scout.hip", "pq2_density.hip", "pq2_optional.hip", "pq2_noalloc.hip", "pq2_api.cpp", "pq2_host.cpp"]
 HEADERS = ["pq2_device.h", "pq2_ring.h", os.path.join("..", "..", "include", "pq2hip.h")]
 DEPS = SOURCES + HEADERS
 

@@ -42,6 +42,8 @@ hipError_t pq2_launch_filtered(const void *pieces, uint32_t n_pieces, uint32_t *
 hipError_t pq2_launch_optional(const void *pages, uint32_t n_pages, uint32_t value_words, int32_t *status,
                                uint32_t seg_rows, uint32_t n_segs, uint32_t *seg_valid,
                                hipStream_t stream);
+hipError_t pq2_launch_optional_bits(const void *pages, uint32_t n_pages, uint32_t value_words, int32_t *status,
+                                    const int32_t *level_status, uint64_t dict_bytes, hipStream_t stream);
 hipError_t pq2_launch_bitunpack64(const void *d_packed, uint32_t packed_len, uint32_t num_bits, uint32_t length,
                                   uint64_t *d_out, hipStream_t stream);
 hipError_t pq2_launch_delta(const void *pages, uint32_t n_pages, void *results, hipStream_t stream);
@@ -248,6 +250,10 @@ struct pq2_ctx {
     int32_t *h_status = nullptr;  // page-locked: a copy into the caller's (pageable) array would block every chunk
     size_t h_status_cap = 0;
     hipStream_t lane_stream = nullptr;  // of a child context
+    // pq2_decode_optional_dict_batch_device: the child context that turns the level streams into validity bitmaps on a
+    // stream of its own while this one decodes the indices, and the events between the two streams
+    pq2_ctx *bits_lane = nullptr;
+    hipEvent_t bits_fork = nullptr, bits_joined = nullptr;
 };
 
 namespace {
@@ -802,6 +808,9 @@ int32_t pq2_ctx_destroy(pq2_ctx *ctx) {
     }
     for (pq2_ctx *lane : ctx->lanes)
         if (lane) (void)pq2_ctx_destroy(lane);
+    if (ctx->bits_lane) (void)pq2_ctx_destroy(ctx->bits_lane);
+    for (hipEvent_t e : {ctx->bits_fork, ctx->bits_joined})
+        if (e) (void)hipEventDestroy(e);
     if (ctx->h_status) (void)hipHostFree(ctx->h_status);
     if (ctx->lane_stream) (void)hipStreamDestroy(ctx->lane_stream);
     delete ctx;
@@ -1005,6 +1014,94 @@ int32_t pq2_decode_optional_dict_batch_device(pq2_ctx *ctx, const void *d_in, ui
         return fail(ctx, PQ2_INVALID_PARAMETER, "a descriptor array is NULL");
     if ((reinterpret_cast<uintptr_t>(d_out) & 3u) != 0 || (reinterpret_cast<uintptr_t>(d_dict) & 3u) != 0)
         return fail(ctx, PQ2_INVALID_PARAMETER, "d_out / d_dict misaligned");
+    // Flat nullable columns (every maximum level 1, the streams one bit wide), enough pages for a workgroup each: the
+    // levels are not expanded at all.  A child context turns the level streams into validity bitmaps (ring_kernel's
+    // bitmap mode, which is bound by the header walks and moves next to nothing) on a stream of its own while this
+    // context decodes the index streams, and the scatter reads one bit per row instead of a u32 that had to be written
+    // first.  Same values, validity and statuses as the path below (a level is valid where it equals 1 either way).
+    static const bool bits_knob = [] {  // PQ2_OPTIONAL_BITS=0: levels as u32 (A/B runs)
+        const char *v = std::getenv("PQ2_OPTIONAL_BITS");
+        return !v || std::atoi(v) != 0;
+    }();
+    bool by_bits = bits_knob && n_pages >= kOptionalWholePages &&
+                   (ctx->mode == pq2_ctx::kAuto || ctx->mode == pq2_ctx::kRing);
+    for (uint64_t i = 0; by_bits && i < n_pages; ++i)
+        by_bits = max_def_levels[i] == 1 && def_descs[i].num_bits == 1 && def_descs[i].num_values <= PQ2_MAX_PAGE_VALUES &&
+                  // (optional_bits_kernel reads indices and dictionaries through 32-bit byte offsets)
+                  idx_descs[i].num_values < (1u << 30) && uint64_t(dicts[i].dict_len) * value_size < (1ull << 32);
+    if (by_bits) {
+        int32_t st;
+        for (uint64_t i = 0; i < n_pages; ++i) {
+            const pq2_dict_ref &r = dicts[i];
+            if (r.dict_off % 4 != 0) return fail(ctx, PQ2_INVALID_PARAMETER, "dictionary offset misaligned");
+            if (r.dict_off > dict_bytes || uint64_t(r.dict_len) * value_size > dict_bytes - r.dict_off)
+                return fail(ctx, PQ2_INVALID_PARAMETER, "dictionary outside the dictionary buffer");
+            if (def_descs[i].out_off > out_rows || def_descs[i].num_values > out_rows - def_descs[i].out_off)
+                return fail(ctx, PQ2_INVALID_PARAMETER, "page rows outside the output buffer");
+        }
+        if (!ctx->bits_lane) {
+            if ((st = pq2_ctx_create(ctx->device, &ctx->bits_lane))) return fail(ctx, st, "cannot create the context of the level streams");
+            ctx->bits_lane->profiling = false;
+            PQ2_HIP(ctx, hipStreamCreateWithFlags(&ctx->bits_lane->lane_stream, hipStreamNonBlocking));
+            PQ2_HIP(ctx, hipEventCreateWithFlags(&ctx->bits_fork, hipEventDisableTiming));
+            PQ2_HIP(ctx, hipEventCreateWithFlags(&ctx->bits_joined, hipEventDisableTiming));
+        }
+        pq2_ctx *const lane = ctx->bits_lane;
+        std::vector<pq2_page_desc> levels(def_descs, def_descs + n_pages), indices(idx_descs, idx_descs + n_pages);
+        uint64_t bitmap_bytes = 0, idx_values = 0;
+        for (uint64_t i = 0; i < n_pages; ++i) {
+            levels[i].out_off = bitmap_bytes;  // (bytes)
+            bitmap_bytes += (def_descs[i].num_values + 31) / 32 * 4;
+            indices[i].out_off = idx_values;
+            idx_values += (idx_descs[i].num_values + 3) & ~uint64_t(3);
+        }
+        if (ctx->busy && ctx->last_stream != stream) PQ2_HIP(ctx, hipStreamSynchronize(ctx->last_stream));
+        if ((st = reserve(ctx, lane->d_out, std::max<uint64_t>(bitmap_bytes, 4)))) return st;
+        // (optional_bits_kernel reads 16 bytes at a time from any index of a page on: 12 bytes behind the last page's)
+        if ((st = reserve(ctx, ctx->d_indices, std::max<uint64_t>(idx_values, 1) * sizeof(uint32_t) + 16))) return st;
+        // The index streams first: where this context looks at the headers before it settles on a schedule, that look
+        // should not have to wait for a compute unit behind the workgroups of the level streams.  Then the level
+        // streams on the child's stream, behind whatever the caller's stream held at the call.
+        PQ2_HIP(ctx, hipEventRecord(ctx->bits_fork, stream));
+        uint32_t *d_idx = static_cast<uint32_t *>(ctx->d_indices.ptr);
+        if ((st = enqueue_batch(ctx, d_in, in_bytes, indices.data(), n_pages, d_idx, idx_values, stream))) return st;
+        PQ2_HIP(ctx, hipStreamWaitEvent(lane->lane_stream, ctx->bits_fork, 0));
+        st = pq2_decode_validity_bitmap_batch_device(lane, d_in, in_bytes, levels.data(), n_pages, lane->d_out.ptr,
+                                                     std::max<uint64_t>(bitmap_bytes, 4), nullptr, nullptr, nullptr,
+                                                     lane->lane_stream);
+        if (st != PQ2_OK) return fail(ctx, st, pq2_last_error(lane));
+        PQ2_HIP(ctx, hipEventRecord(ctx->bits_joined, lane->lane_stream));
+        PQ2_HIP(ctx, hipStreamWaitEvent(stream, ctx->bits_joined, 0));
+        const size_t bytes = n_pages * sizeof(OptionalPage);
+        if ((st = stage_block(ctx, bytes, bytes))) return st;
+        OptionalPage *g = static_cast<OptionalPage *>(ctx->h_gather);
+        uint64_t largest_dict = 0;  // bytes
+        for (uint64_t i = 0; i < n_pages; ++i) {
+            const bool skip = ctx->host_status[i] != PQ2_OK || lane->host_status[i] != PQ2_OK;
+            largest_dict = std::max<uint64_t>(largest_dict, uint64_t(dicts[i].dict_len) * value_size);
+            g[i].level_addr = reinterpret_cast<uint64_t>(lane->d_out.ptr) + levels[i].out_off;
+            g[i].idx_addr = reinterpret_cast<uint64_t>(d_idx + indices[i].out_off);
+            g[i].out_addr = reinterpret_cast<uint64_t>(d_out) + def_descs[i].out_off * value_size;
+            g[i].validity_addr = reinterpret_cast<uint64_t>(d_validity) + def_descs[i].out_off;
+            g[i].dict_addr = reinterpret_cast<uint64_t>(d_dict) + dicts[i].dict_off;
+            g[i].rows = skip ? 0u : static_cast<uint32_t>(def_descs[i].num_values);
+            g[i].idx_values = static_cast<uint32_t>(idx_descs[i].num_values);
+            g[i].dict_len = dicts[i].dict_len;
+            g[i].max_level = 1;
+            g[i].idx_status_at = static_cast<uint32_t>(i);
+            g[i].first_seg = 0;
+            // a page's own status (its level stream's), or else its index stream's
+            if (lane->host_status[i] != PQ2_OK) ctx->host_status[i] = lane->host_status[i];
+        }
+        if ((st = upload_block(ctx, bytes, stream))) return st;
+        PQ2_HIP(ctx, pq2_launch_optional_bits(ctx->d_gather.ptr, static_cast<uint32_t>(n_pages), value_size / 4,
+                                              static_cast<int32_t *>(ctx->d_status.ptr),
+                                              static_cast<const int32_t *>(lane->d_status.ptr), largest_dict, stream));
+        ctx->last_schedule = "ring_kernel (indices) + ring_kernel+bitmap (levels)";
+        ctx->last_n_pages = n_pages;
+        if (status) return fetch_status(ctx, status, n_pages);
+        return PQ2_OK;
+    }
     // the level and index streams of all pages as one batch of 2 * n_pages streams decoded into the context's buffer
     std::vector<pq2_page_desc> both(2 * n_pages);
     uint64_t at = 0;

@@ -98,6 +98,16 @@ constexpr uint32_t kRemMask = 0x7fffffffu;
 
 enum RunKind : uint32_t { kBitpacked = 0, kRle = 1, kEnd = 2, kPanic = 3 };
 
+// A nullable dictionary page after its two streams are decoded (optional_kernel, optional_bits_kernel).
+struct OptionalPage {  // must match the host's
+    uint64_t level_addr;  // decoded levels: u32, one per row, 16-byte aligned; or the validity bitmap, row r at bit r % 32 of word r / 32
+    uint64_t idx_addr;    // decoded indices (u32)
+    uint64_t out_addr, validity_addr, dict_addr;
+    uint32_t rows, idx_values, dict_len, max_level;
+    uint32_t idx_status_at;  // where the index stream's status lies in the status array
+    uint32_t first_seg;      // batch-wide number of the page's first segment of `seg_rows` rows
+};
+
 struct RunInfo {
     uint32_t kind;     // RunKind
     uint32_t count;    // values the run yields, already clamped to `remaining`

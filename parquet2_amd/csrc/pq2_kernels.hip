@@ -1157,15 +1157,6 @@ __global__ __launch_bounds__(256) void gather_kernel(const GatherPage *__restric
 // flight together), carrying the count of valid rows: a prefix sum over the
 // lanes of a wave, the wave totals through LDS, one barrier per step.
 // ---------------------------------------------------------------------------
-struct OptionalPage {  // must match the host's
-    uint64_t level_addr;  // decoded levels (u32), one per row; 16-byte aligned
-    uint64_t idx_addr;    // decoded indices (u32)
-    uint64_t out_addr, validity_addr, dict_addr;
-    uint32_t rows, idx_values, dict_len, max_level;
-    uint32_t idx_status_at;  // where the index stream's status lies in the status array
-    uint32_t first_seg;      // batch-wide number of the page's first segment of `seg_rows` rows
-};
-
 // Which page segment `seg` belongs to: the last one whose first segment is not behind it (pages without rows share
 // their successor's).
 __device__ __forceinline__ uint32_t optional_page_of(const OptionalPage *__restrict__ pages, uint32_t n_pages, uint32_t seg) {

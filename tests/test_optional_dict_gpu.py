@@ -204,3 +204,56 @@ def test_statuses(ctx, oracle):
     assert (validity[o:o + 64] == 0).all() and (got[o:o + 64] == 0).all()
     o = b.defs[4][4]
     assert (validity[o:o + rows] == short_levels).all() and (got[o:o + few, 0] == table[3, 0]).all()
+
+
+@pytest.mark.parametrize("value_size,idx_bits", [(4, 8), (8, 9), (12, 12)])
+def test_flat_nullable_batches_read_their_levels_as_bitmaps(oracle, value_size, idx_bits):
+    """From 256 pages on, a batch of flat nullable pages (every maximum level 1) has its level streams turned into
+    validity bitmaps and optional_bits_kernel reads those: same values, validity and statuses.  Pages of one row to
+    several steps of 4096 rows, outputs that are not aligned, dictionaries that fit the workgroups' LDS (8 and 9 bits)
+    and one that does not (12 bits x 12 bytes), index streams shorter than the valid rows, and the failures: an
+    index stream and a level stream the reference panics on, a dictionary that misses a consumed index."""
+    from parquet2_amd import Context
+
+    rng = np.random.default_rng(1000 + value_size)
+    words = value_size // 4
+    table = rng.integers(0, 1 << 32, size=(1 << idx_bits, words), dtype=np.uint64).astype(np.uint32)
+    b = Batch()
+    pages, want_status = [], []
+    sizes = [1, 3, 4, 5, 4095, 4096, 4097, 8192, 12288, 12289, 300000] + [int(rng.integers(1, 30000)) for _ in range(300)]
+    panics = np.frombuffer(b"\x80" * 9 + b"\x02" + b"\x01", dtype=np.uint8)
+    for p, rows in enumerate(sizes):
+        null_run = 5.0 if p % 7 else 400.0  # (some pages with long stretches of nulls)
+        def_stream, levels = synth.def_levels_page(synth.seed_for(3, 3000 + p), rows, 50.0, null_run)
+        idx_stream, idx = synth.dict_page(synth.seed_for(2, 4000 + p), rows, idx_bits, 6.0, 20.0)
+        idx_values, dict_len, st = rows, len(table), OK
+        n_valid = int((levels == 1).sum())
+        if p % 11 == 3:
+            idx_values = n_valid // 2  # fewer indices than valid rows: the rows behind them stay null
+        elif p == 20:
+            idx_stream, st = np.array([0x10, 1], dtype=np.uint8), REFERENCE_WOULD_PANIC
+        elif p == 21:
+            def_stream, st = panics, REFERENCE_WOULD_PANIC
+        elif p == 22 and n_valid > 0:
+            dict_len, st = int(idx[:n_valid].max()), OUT_OF_SPEC
+        args = (def_stream, 1, rows, idx_stream, 12 if p == 20 else idx_bits, idx_values)
+        b.add(*args, (0, dict_len, 0), gap=p % 3)
+        pages.append((args, dict_len))
+        want_status.append(st)
+    ctx = Context(0)
+    try:
+        got, validity, status = b.run(ctx, table.view(np.uint8).reshape(-1), value_size)
+        assert "bitmap" in ctx.last_schedule(), ctx.last_schedule()
+    finally:
+        ctx.close()
+    assert list(status) == want_status
+    covered = np.zeros(b.rows, dtype=bool)
+    for k, (d, (args, dict_len)) in enumerate(zip(b.defs, pages)):
+        o, rows = d[4], d[3]
+        covered[o:o + rows] = True
+        if want_status[k] == REFERENCE_WOULD_PANIC:
+            continue
+        out, present, bad = expected(oracle, *args, table[:dict_len])
+        assert bad == (want_status[k] == OUT_OF_SPEC), k
+        assert (validity[o:o + rows] == present).all() and (got[o:o + rows] == out).all(), (k, rows)
+    assert (got[~covered] == 0x5A5A5A5A).all() and (validity[~covered] == 7).all()

@@ -196,6 +196,8 @@ def traffic_from_profiles(workload_key, kernel_name):
             continue
         try:
             t = json.load(open(path))
+            if "+" in kernel_name and kernel_name not in t:
+                kernel_name = "all_pq2_kernels"  # a schedule of several kernels: what they move together
             if t["workload"] == workload_key and kernel_name in t:
                 e = t[kernel_name]
                 per_launch = (e["fetch_bytes_per_step"] + e["write_bytes_per_step"]) // max(e["launches_per_step"], 1)

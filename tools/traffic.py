@@ -31,5 +31,9 @@ for k in sorted(set(fetch) | set(write)):
     out[k] = {"launches_per_step": fetch[k][1] // batches,
               "fetch_bytes_per_step": int(2 * fetch[k][0] / batches),
               "write_bytes_per_step": int(write[k][0] / batches)}
+# every pq2 kernel of a step together: what a schedule of several kernels ("scout+expand_kernel") moves
+out["all_pq2_kernels"] = {"launches_per_step": 1,
+                          "fetch_bytes_per_step": sum(out[k]["fetch_bytes_per_step"] for k in sorted(set(fetch) | set(write))),
+                          "write_bytes_per_step": sum(out[k]["write_bytes_per_step"] for k in sorted(set(fetch) | set(write)))}
 json.dump(out, open(sys.argv[4], "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -68,6 +68,9 @@ def parse_args():
                     choices=["dict", "def", "defbits", "adversarial", "bitpacked", "mixed5", "bitunpack"],
                     help="one workload only (default: dict, with the other configs' results under other_configs)")
     ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--page-latency", action="store_true",
+                    help="one page per call, host memory to host memory (what a per-page HybridRleDecoder::try_new "
+                         "costs), beside the CPU port on the same page")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-path", action="store_true",
                     help="time pq2_decode_batch_host instead (page-locked host buffers in, host buffers out: the "
@@ -206,6 +209,34 @@ def traffic_from_profiles(workload_key, kernel_name):
         except (OSError, KeyError, ValueError):
             continue
     return None, None
+
+
+def bench_page_latency(ctx):
+    """HybridRleDecoder::try_new(data, w, n).collect() one page at a time through pq2_decode_batch_host (stream up,
+    decode, values and status down) against the CPU port on the same page: where a per-page binding starts to pay."""
+    orc, flags = load_oracle()
+    rows = []
+    for n in (10, 1000, 16384, 65536, 262144, 1 << 20, 1 << 22):
+        stream_bytes, vals = synth.dict_page(synth.seed_for(2, 7), n, 12)
+        out, st = ctx.decode_page_host(stream_bytes, 12, n)
+        assert st == 0 and np.array_equal(out, vals)
+        st, ref = orc.hybrid_rle_decode(stream_bytes, 12, n)
+        assert st == 0 and np.array_equal(ref, vals)
+        reps = 200 if n <= 65536 else 30
+        gpu, cpu = [], []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            ctx.decode_page_host(stream_bytes, 12, n)
+            gpu.append(time.perf_counter() - t0)
+            t0 = time.perf_counter()
+            orc.hybrid_rle_decode(stream_bytes, 12, n)
+            cpu.append(time.perf_counter() - t0)
+        rows.append({"values": n, "stream_bytes": int(len(stream_bytes)), "gpu_call_us": round(1e6 * float(np.median(gpu)), 1),
+                     "cpu_port_us": round(1e6 * float(np.median(cpu)), 1)})
+    return {"metric": "one page per call, host memory to host memory, microseconds (median)", "config": {
+        "workload": "RLE_DICTIONARY index pages, bit width 12, mixed runs; pageable host buffers, numpy wrapper included "
+                    "on both sides (an output array is allocated per call)"},
+        "cpu": "C port of HybridRleDecoder drained per value (%s), one thread" % flags, "pages": rows}
 
 
 def bench_bitunpack(args, dev, ctx, stream):
@@ -564,6 +595,10 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     env = {"ctx": ctx, "dev": dev, "stream": stream, "rank": rank, "world": world, "dist": dist, "backend": backend}
 
+    if args.page_latency:
+        print(json.dumps(bench_page_latency(ctx)), flush=True)
+        ctx.close()
+        return
     if args.workload == "bitunpack":
         print(json.dumps(bench_bitunpack(args, dev, ctx, stream)), flush=True)
         ctx.close()

@@ -6,7 +6,7 @@
 //   pattern 2: as 1, each workgroup beginning at another offset of its region (regions that are a power of two
 //              apart, walked in step, meet in the same memory channels).
 // Build: hipcc -O3 --offload-arch=gfx950 tools/stream_pattern.hip -o gpurun_out/stream_pattern
-// Run:   gpurun_out/stream_pattern [regions = 2048] [workgroups = 1024] [threads = 256 | 128]
+// Run:   gpurun_out/stream_pattern [regions = 2048] [workgroups = 1024] [threads = 256 | 128] [more: patterns 3 and 4]
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -91,6 +91,74 @@ static double run(const uint8_t *in, uint8_t *out, uint32_t regions, uint32_t gr
     return ms / reps;
 }
 
+// ---- what round 1's tools/ubench/membw.hip measured (5.5-5.7 TB/s for 1 read : 4 written), in this file's terms ------
+// pattern 3: no workgroup stays: a grid of total_steps / per workgroups, each doing `per` consecutive steps of kStep
+//            bytes written (and 3/8 of that read) and ending -- the hardware hands the pieces out in order, so all that
+//            is written at one time lies in one window that moves through memory once.
+// pattern 4: a region per workgroup as pattern 1, with the step size as a parameter (4 ... 64 KiB written per step) and
+//            the loads marked non-temporal or not.
+template <int kThreads, uint32_t kStep, bool kNtLoad>
+__device__ __forceinline__ void one_step(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, uint64_t step) {
+    constexpr uint32_t kIn = kStep * 3u / 8u;
+    const uint32_t tid = threadIdx.x;
+    const uint8_t *const src = in + step * kIn;
+    uint8_t *const dst = out + step * kStep;
+    u32x4 v = {0, 0, 0, 0};
+#pragma unroll
+    for (uint32_t k = 0; k * kThreads * 16u < kIn; ++k)
+        if ((tid + k * kThreads) * 16u < kIn) {
+            const u32x4 *const p = (const u32x4 *)(src + 16u * (tid + k * kThreads));
+            v ^= kNtLoad ? __builtin_nontemporal_load(p) : *p;
+        }
+#pragma unroll
+    for (uint32_t k = 0; k * kThreads * 16u < kStep; ++k) {
+        const u32x4 o = {v.x + k, v.y, v.z, v.w};
+        __builtin_nontemporal_store(o, (u32x4 *)(dst + 16u * (tid + kThreads * k)));
+    }
+}
+template <int kThreads, uint32_t kStep, bool kNtLoad>
+__global__ __launch_bounds__(kThreads) void once_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, uint32_t per) {
+    for (uint32_t i = 0; i < per; ++i) one_step<kThreads, kStep, kNtLoad>(in, out, (uint64_t)blockIdx.x * per + i);
+}
+template <int kThreads, uint32_t kStep, bool kNtLoad>
+__global__ __launch_bounds__(kThreads) void region_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
+                                                          uint32_t n_regions, uint32_t region_steps) {
+    for (uint32_t region = blockIdx.x; region < n_regions; region += gridDim.x)
+        for (uint32_t i = 0; i < region_steps; ++i)
+            one_step<kThreads, kStep, kNtLoad>(in, out, (uint64_t)region * region_steps + i);
+}
+template <typename Launch>
+static double timed(Launch launch, int reps) {
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    launch();
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0, 0));
+    for (int r = 0; r < reps; ++r) launch();
+    CHECK(hipEventRecord(e1, 0));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / reps;
+}
+template <int kThreads, uint32_t kStep, bool kNtLoad>
+static void more_patterns(const uint8_t *in, uint8_t *out, uint32_t regions, uint32_t grid) {
+    const uint64_t out_bytes = (uint64_t)regions * kRegionOut;
+    const uint64_t steps = out_bytes / kStep;
+    const double bytes = (double)out_bytes * 11.0 / 8.0;
+    for (uint32_t per : {1u, 4u, 16u, 64u}) {
+        if (steps % per) continue;
+        const double ms = timed([&] { hipLaunchKernelGGL((once_kernel<kThreads, kStep, kNtLoad>), dim3((uint32_t)(steps / per)), dim3(kThreads), 0, 0, in, out, per); }, 5);
+        printf("pattern 3 (one pass, %u steps of %u KiB per workgroup of %d%s): %.3f ms, %.2f TB/s (%.3f of 8 TB/s)\n", per, kStep >> 10,
+               kThreads, kNtLoad ? ", nt loads" : "", ms, bytes / ms * 1e-9, bytes / ms * 1e-9 / 8.0);
+    }
+    const uint32_t region_steps = (uint32_t)(kRegionOut / kStep);
+    const double ms = timed([&] { hipLaunchKernelGGL((region_kernel<kThreads, kStep, kNtLoad>), dim3(grid), dim3(kThreads), 0, 0, in, out, regions, region_steps); }, 5);
+    printf("pattern 4 (a region per workgroup, steps of %u KiB, %u workgroups of %d%s): %.3f ms, %.2f TB/s (%.3f of 8 TB/s)\n", kStep >> 10, grid,
+           kThreads, kNtLoad ? ", nt loads" : "", ms, bytes / ms * 1e-9, bytes / ms * 1e-9 / 8.0);
+}
+
 int main(int argc, char **argv) {
     const uint32_t regions = argc > 1 ? (uint32_t)atoi(argv[1]) : 2048u;
     const uint32_t grid = argc > 2 ? (uint32_t)atoi(argv[2]) : 1024u;
@@ -146,6 +214,15 @@ int main(int argc, char **argv) {
             printf("%s of %.1f GB: %.3f ms, %.2f TB/s%s\n", dir == 0 ? "hipMemsetAsync" : "hipMemcpyAsync (half onto half)",
                    gib8 * 1e-9, ms, gib8 / ms * 1e-9, dir == 0 ? " written" : " read + written");
         }
+    }
+    if (argc > 4) {  // the further patterns
+        more_patterns<256, 4096, false>(in, out, regions, grid);
+        more_patterns<256, 16384, false>(in, out, regions, grid);
+        more_patterns<256, 16384, true>(in, out, regions, grid);
+        more_patterns<256, 65536, false>(in, out, regions, grid);
+        more_patterns<128, 4096, false>(in, out, regions, grid);
+        more_patterns<128, 16384, true>(in, out, regions, grid);
+        more_patterns<128, 65536, true>(in, out, regions, grid);
     }
     CHECK(hipFree(in));
     CHECK(hipFree(out));

@@ -1657,6 +1657,10 @@ struct RingDict {
     uint32_t dict_len;
     uint32_t num_values, first_tile, reserved;  // not used here
 };
+constexpr uint32_t kRingFlagWholeTileSpans = 1u;  // ring_kernel's `flags`: a batch of nothing but levels (see kRingWholeTileBits)
+constexpr uint32_t kRingFlagTurns = 2u;           // ... the workgroups of a compute unit take turns in priority
+constexpr uint32_t kRingTurnsMaxBits = 20;        // the widest page of a batch that is given turns
+constexpr uint32_t kRingTurnsMinPages = 1025;     // ... and its fewest pages: one more than 256 compute units hold workgroups
 constexpr uint32_t kRingDictMaxBits = 12;  // widest index the kernels with a dictionary are built for
 
 // kWords = 0: the page's values are the decoded u32 (IndexSink).  kWords = 1, 2, 3: they are indices into the page's
@@ -1670,7 +1674,7 @@ __global__ __launch_bounds__(kRingThreads, PQ2_RING_MIN_WAVES) void ring_kernel(
                                                        int32_t *__restrict__ status, uint32_t *__restrict__ cu_tickets,
                                                        uint32_t ring_bytes, const uint32_t *__restrict__ tile_mask,
                                                        const RingDict *__restrict__ dicts, uint32_t dict_at,
-                                                       uint32_t whole_tile_spans, uint32_t epoch,
+                                                       uint32_t flags, uint32_t epoch,
                                                        uint32_t *__restrict__ bit_meta, const uint32_t *__restrict__ go) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     // a launch that was enqueued before the batch's schedule was final (density_kernel, pq2_density.hip) and has
@@ -1731,9 +1735,14 @@ __global__ __launch_bounds__(kRingThreads, PQ2_RING_MIN_WAVES) void ring_kernel(
     // the order the hardware would give them anyway, first come first; their successors (4-7, 12-15, ...), which
     // begin one after the other as those end, get the reverse.  The walking wave keeps at least the priority it
     // had before there were turns: a page's walk is its serial part.
+    // Only where there is something to turn round (kRingFlagTurns: the launcher sets it for batches of more pages than
+    // the GPU holds workgroups, and of widths up to 20 bits -- wider pages, whose expanding waves are short of
+    // instruction issue rather than of memory, lose 1-4 % by it, a batch of nothing but level pages 2 %, and a batch
+    // of one round up to 7 %).
 #if PQ2_RING_PRIO_TURNS
     const uint32_t rank = ticket & 3u;
-    const uint32_t turn = (((ticket & 4u) ? PQ2_RING_PRIO_SECOND : PQ2_RING_PRIO_FIRST) >> (4u * rank)) & 3u;
+    uint32_t turn = (((ticket & 4u) ? PQ2_RING_PRIO_SECOND : PQ2_RING_PRIO_FIRST) >> (4u * rank)) & 3u;
+    if ((flags & kRingFlagTurns) == 0u) turn = 0u;
     const uint32_t prio_walk = max(turn, (uint32_t)PQ2_RING_WALK_PRIO), prio_expand = turn;
 #else
     const uint32_t prio_walk = PQ2_RING_WALK_PRIO, prio_expand = 0u;
@@ -1783,11 +1792,11 @@ __global__ __launch_bounds__(kRingThreads, PQ2_RING_MIN_WAVES) void ring_kernel(
             const uint32_t tile_first = t * kRingTileValues;
             out_u32 *const out = (out_u32 *)pg.out_addr + tile_first;
             // pages of levels: the tile as one span
-            // (`whole_tile_spans`: the launcher says so for batches of nothing but such pages; beside wider pages the
+            // (kRingFlagWholeTileSpans: the launcher says so for batches of nothing but such pages; beside wider pages the
             // whole-tile spans cost more than they bring: configs[4]'s mix loses 2.6 % with them)
             const uint32_t span_blocks =
                 kWords < 0 ? kRingTileBlocks
-                : (kWords == 0 && kRingTileBlocks == 4 && whole_tile_spans != 0u && w != 0u && w <= kRingWholeTileBits) ? 4u : kRingSpanBlocks;
+                : (kWords == 0 && kRingTileBlocks == 4 && (flags & kRingFlagWholeTileSpans) != 0u && w != 0u && w <= kRingWholeTileBits) ? 4u : kRingSpanBlocks;
             const uint32_t span_values = span_blocks * kBlockValues;
             for (uint32_t i = 0; i < kRingTileBlocks / span_blocks; ++i) {
                 const uint32_t span_first = tile_first + i * span_values;

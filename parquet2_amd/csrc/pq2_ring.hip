@@ -37,7 +37,10 @@ extern "C" hipError_t pq2_launch_ring(const void *pages, uint32_t n_pages, int32
     }
     const uint32_t lds_bytes = pq2::ring_lds_bytes(ring_bytes);
     // a batch of nothing but levels: whole tiles as spans (see kRingWholeTileBits)
-    const uint32_t whole_tile_spans = max_bits != 0u && max_bits <= pq2::kRingWholeTileBits ? 1u : 0u;
+    const uint32_t flags = (max_bits != 0u && max_bits <= pq2::kRingWholeTileBits ? pq2::kRingFlagWholeTileSpans : 0u) |
+                           (n_pages >= pq2::kRingTurnsMinPages && max_bits > pq2::kRingWholeTileBits && max_bits <= pq2::kRingTurnsMaxBits
+                                ? pq2::kRingFlagTurns
+                                : 0u);
     if (max_bits > pq2::kRingNarrowBits) {  // ring_kernel<true, .>: every width, and a header walk that keeps four more bytes per run
         // more than 64 KiB of dynamic LDS has to be asked for (per device; the call is cheap)
         if (lds_bytes > 65536u) {
@@ -47,11 +50,11 @@ extern "C" hipError_t pq2_launch_ring(const void *pages, uint32_t n_pages, int32
         }
         hipLaunchKernelGGL((pq2::ring_kernel<true, 0>), dim3(n_pages), dim3(pq2::kRingThreads), lds_bytes, stream,
                            (const pq2::PageDev *)pages, n_pages, status, cu_tickets, ring_bytes, tile_mask,
-                           (const pq2::RingDict *)nullptr, 0u, whole_tile_spans, epoch, (uint32_t *)nullptr, go);
+                           (const pq2::RingDict *)nullptr, 0u, flags, epoch, (uint32_t *)nullptr, go);
     } else {
         hipLaunchKernelGGL((pq2::ring_kernel<false, 0>), dim3(n_pages), dim3(pq2::kRingThreads), lds_bytes, stream,
                            (const pq2::PageDev *)pages, n_pages, status, cu_tickets, ring_bytes, tile_mask,
-                           (const pq2::RingDict *)nullptr, 0u, whole_tile_spans, epoch, (uint32_t *)nullptr, go);
+                           (const pq2::RingDict *)nullptr, 0u, flags, epoch, (uint32_t *)nullptr, go);
     }
     return hipGetLastError();
 }

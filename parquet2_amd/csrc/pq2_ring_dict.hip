@@ -31,6 +31,7 @@ extern "C" hipError_t pq2_launch_ring_dict(const void *pages, uint32_t n_pages, 
     const uint32_t dict_at = pq2::ring_lds_bytes(ring_bytes);
     static_assert(pq2::ring_lds_bytes(16384u) % 16u == 0u, "the dictionary begins at a 16-byte boundary");
     const uint32_t lds_bytes = dict_at + dict_bytes;
+    const uint32_t flags = n_pages >= pq2::kRingTurnsMinPages ? pq2::kRingFlagTurns : 0u;  // (indices of at most 12 bits)
 #define PQ2_LAUNCH(WORDS)                                                                                             \
     if (lds_bytes > 65536u) { /* more than 64 KiB of dynamic LDS has to be asked for */                               \
         hipError_t e = hipFuncSetAttribute((const void *)pq2::ring_kernel<false, WORDS>,                              \
@@ -39,7 +40,7 @@ extern "C" hipError_t pq2_launch_ring_dict(const void *pages, uint32_t n_pages, 
     }                                                                                                                 \
     hipLaunchKernelGGL((pq2::ring_kernel<false, WORDS>), dim3(n_pages), dim3(pq2::kRingThreads), lds_bytes, stream,   \
                        (const pq2::PageDev *)pages, n_pages, status, cu_tickets, ring_bytes, tile_mask,               \
-                       (const pq2::RingDict *)dicts, dict_at, 0u, epoch, (uint32_t *)nullptr, (const uint32_t *)nullptr)
+                       (const pq2::RingDict *)dicts, dict_at, flags, epoch, (uint32_t *)nullptr, (const uint32_t *)nullptr)
     if (value_words == 1u) {
         PQ2_LAUNCH(1);
     } else if (value_words == 2u) {

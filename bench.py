@@ -68,6 +68,9 @@ def parse_args():
                     choices=["dict", "def", "defbits", "adversarial", "bitpacked", "mixed5", "bitunpack"],
                     help="one workload only (default: dict, with the other configs' results under other_configs)")
     ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--level-bits", type=int, default=1,
+                    help="bit width of the level pages of --workload def (1: BASELINE configs[2]; 2, 3: columns "
+                         "that are optional inside optional or repeated ones)")
     ap.add_argument("--page-latency", action="store_true",
                     help="one page per call, host memory to host memory (what a per-page HybridRleDecoder::try_new "
                          "costs), beside the CPU port on the same page")
@@ -99,6 +102,9 @@ def host_cpus():
     return os.cpu_count() or 1, len(os.sched_getaffinity(0))
 
 
+LEVEL_BITS = 1
+
+
 def make_pool(kind, count, values, bits):
     """`count` different pages of one kind: list of (stream ndarray, expected values ndarray, bit width)."""
     pool = []
@@ -108,6 +114,9 @@ def make_pool(kind, count, values, bits):
         elif kind in ("def", "defbits"):
             s, v = synth.def_levels_page(synth.seed_for(3, p), values)
             bits = 1
+            if LEVEL_BITS > 1:  # --level-bits: the same runs with the valid rows at the maximum level of that width
+                v = v * np.uint32((1 << LEVEL_BITS) - 1)
+                s, bits = synth.encode_hybrid(v, LEVEL_BITS), LEVEL_BITS
         elif kind == "adversarial":
             s, v = synth.adversarial(synth.seed_for(4, p), values, bits)
         else:  # one bit-packed run, as the reference's own encoder writes pages
@@ -517,7 +526,7 @@ def run_pages(a, env):
         expand_avg_ms = (parse_ms + expand_ms) / max(batches, 1)
     achieved = bytes_per_launch / (expand_avg_ms * 1e-3) / 1e9
     workload_key = {"workload": a.workload, "pages_per_gpu": a.pages, "values_per_page": n,
-                    "num_bits": a.bits if a.workload not in ("def", "defbits") else 1}
+                    "num_bits": a.bits if a.workload not in ("def", "defbits") else LEVEL_BITS}
     traffic, traffic_source = traffic_from_profiles(workload_key, kernel_name)
     result = {
         "metric": "device-resident validity-bitmap decode, 10^9 rows/s (DefLevelsDecoder::Bitmap)" if as_bits else METRIC,
@@ -569,6 +578,8 @@ def brief(line):
 
 def main():
     args = parse_args()
+    global LEVEL_BITS
+    LEVEL_BITS = args.level_bits
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -81,10 +81,12 @@ constexpr uint32_t kRingTableRuns = 64;                      // run-table entrie
 // chunk-index entry -- or, for pages of at most kRingWholeTileBits bits (definition and repetition levels: long
 // RLE runs, little of the ring in use), the whole tile of 4 blocks with one byte per entry: half as many spans to
 // set up, and the same LDS.  (Measured: config 3 gains 8 %; config-2 pages lose 12 % with whole-tile spans, because
-// a wave then holds on to the ring bytes of a whole tile.)
+// a wave then holds on to the ring bytes of a whole tile.  Width 1 only: at width 2, where the values go through
+// ring_expand_span and not through their bits, level pages of 2^20 rows reach 0.64 of peak with spans of 2 blocks
+// and 0.53 with whole tiles, index-shaped pages 0.59 against 0.48; only pages of 65 536 levels gain, 2 %.)
 constexpr uint32_t kRingSpanBlocks = 2;
 #ifndef PQ2_RING_WHOLE_TILE_BITS
-#define PQ2_RING_WHOLE_TILE_BITS 2
+#define PQ2_RING_WHOLE_TILE_BITS 1
 #endif
 constexpr uint32_t kRingWholeTileBits = PQ2_RING_WHOLE_TILE_BITS;  // 0, 1 or 2
 static_assert(kRingTileBlocks == 4 || kRingTileBlocks == 2, "tiles of 2 or 4 blocks");

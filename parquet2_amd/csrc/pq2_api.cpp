@@ -60,7 +60,11 @@ hipError_t pq2_launch_ring_bits(const void *pages, uint32_t n_pages, int32_t *st
                                 uint32_t *bit_meta, hipStream_t stream);  // pq2_ring.hip
 hipError_t pq2_launch_ring_dict(const void *pages, uint32_t n_pages, int32_t *status, uint32_t *cu_tickets,
                                 uint32_t epoch, const uint32_t *tile_mask, const void *dicts, uint32_t value_words, uint32_t max_dict_bytes,
-                                hipStream_t stream);
+                                const void *nulls, hipStream_t stream);
+uint32_t pq2_ring_nullable_max_dict_bytes();
+hipError_t pq2_launch_rowdir(const void *nulls, uint32_t n_pages, hipStream_t stream);  // pq2_optional.hip
+uint32_t pq2_rowdir_step();
+hipError_t pq2_launch_nullable_status(int32_t *status, const int32_t *level_status, uint32_t n_pages, hipStream_t stream);
 uint32_t pq2_scout_tile_bytes();  // pq2_scout.hip
 size_t pq2_scout_table_bytes(uint64_t n_stiles);
 size_t pq2_scout_words_bytes(uint64_t n_stiles, uint64_t n_pages);
@@ -159,7 +163,14 @@ struct TileMask {
 struct FusedDict {
     const void *d_dicts;
     uint32_t value_words, max_dict_bytes;
+    const void *d_nulls = nullptr;  // RingNullable records: the values go to the rows of flat nullable pages
 };
+
+struct RingNullable {  // must match pq2::RingNullable
+    uint64_t bitmap_addr, validity_addr, out_addr, rowdir_addr;
+    uint32_t rows, idx_values;
+};
+static_assert(sizeof(RingNullable) == 40, "RingNullable layout");
 
 // What pq2_decode_validity_bitmap_batch_device adds to a batch: the pages come out as validity bitmaps (out_off: the
 // byte at which a page's bitmap begins) and ring_kernel reports two words per page, rows and set bits.
@@ -194,6 +205,7 @@ struct pq2_ctx {
     // pq2_decode_dict_batch_device: the decoded indices, and the per-page gather descriptors (page-locked + device)
     DevBuf d_indices, d_gather, d_seg_valid;
     DevBuf d_bit_meta;  // pq2_decode_validity_bitmap_batch_device: rows and set bits of every page
+    DevBuf d_rowdir;    // pq2_decode_optional_dict_batch_device: the row directories of flat nullable pages (rowdir_kernel)
     // density_kernel (pq2_density.hip): its two counters and the verdict word on the device, the verdict as the host
     // reads it (page-locked, written by the device), the event behind the kernel, a count of its launches
     DevBuf d_density;
@@ -639,7 +651,7 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
                  if (fused)
                      return pq2_launch_ring_dict(d_pages, static_cast<uint32_t>(n_pages), d_status, ring_tickets,
                                                  ctx->ring_epoch++, d_tile_mask, fused->d_dicts, fused->value_words,
-                                                 fused->max_dict_bytes, stream);
+                                                 fused->max_dict_bytes, fused->d_nulls, stream);
                  if (bits)
                      return pq2_launch_ring_bits(d_pages, static_cast<uint32_t>(n_pages), d_status, ring_tickets,
                                                  ctx->ring_epoch++, bits->d_meta, stream);
@@ -716,7 +728,7 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
     ctx->last_n_pages = n_pages;
     ctx->last_scout = scout;
     ctx->last_scout_tiles = stiles;
-    ctx->last_schedule = fused ? "ring_kernel+dictionary" : bits ? "ring_kernel+bitmap" : ring ? "ring_kernel" : per_page ? "decode_kernel" : scout ? "scout+expand_kernel" : "expand_kernel";
+    ctx->last_schedule = fused && fused->d_nulls ? "ring_kernel+dictionary+rows" : fused ? "ring_kernel+dictionary" : bits ? "ring_kernel+bitmap" : ring ? "ring_kernel" : per_page ? "decode_kernel" : scout ? "scout+expand_kernel" : "expand_kernel";
     return PQ2_OK;
 }
 
@@ -789,7 +801,7 @@ int32_t pq2_ctx_destroy(pq2_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     for (DevBuf *b : {&ctx->d_meta, &ctx->d_status, &ctx->d_resume, &ctx->d_tile_page, &ctx->d_run_pos, &ctx->d_state,
-                      &ctx->d_tickets, &ctx->d_scout_table, &ctx->d_scout_words, &ctx->d_seg_valid, &ctx->d_bit_meta, &ctx->d_density, &ctx->d_indices, &ctx->d_gather, &ctx->d_in, &ctx->d_out})
+                      &ctx->d_tickets, &ctx->d_scout_table, &ctx->d_scout_words, &ctx->d_seg_valid, &ctx->d_bit_meta, &ctx->d_rowdir, &ctx->d_density, &ctx->d_indices, &ctx->d_gather, &ctx->d_in, &ctx->d_out})
         if (b->ptr) (void)hipFree(b->ptr);
     for (hipStream_t s : {ctx->parse_stream, ctx->expand_stream[0], ctx->expand_stream[1]})
         if (s) (void)hipStreamDestroy(s);
@@ -1057,6 +1069,80 @@ int32_t pq2_decode_optional_dict_batch_device(pq2_ctx *ctx, const void *d_in, ui
         }
         if (ctx->busy && ctx->last_stream != stream) PQ2_HIP(ctx, hipStreamSynchronize(ctx->last_stream));
         if ((st = reserve(ctx, lane->d_out, std::max<uint64_t>(bitmap_bytes, 4)))) return st;
+        // Where the indices are narrow enough and the dictionaries small enough for the lookup inside ring_kernel, the
+        // indices are not written either: the bitmaps first (and from them, for every page, the rows at which its
+        // spans of 2048 valid rows begin: rowdir_kernel), then ring_kernel over the index streams, whose expanding waves
+        // keep a span's indices in LDS and write the span's ROWS -- values, nulls and validity bytes.  What moves
+        // through device memory is the streams, the bitmaps (a bit per row, written and read) and the result.
+        // (PQ2_OPTIONAL_FUSED=0: the indices go through memory, optional_bits_kernel places them.)
+        static const bool rows_knob = [] {
+            const char *v = std::getenv("PQ2_OPTIONAL_FUSED");
+            return !v || std::atoi(v) != 0;
+        }();
+        uint32_t idx_max_bits = 0;
+        uint64_t dict_max_bytes = 0;
+        for (uint64_t i = 0; i < n_pages; ++i) {
+            idx_max_bits = std::max(idx_max_bits, idx_descs[i].num_bits);  // (a width above 32 fails the page: not here)
+            dict_max_bytes = std::max<uint64_t>(dict_max_bytes, uint64_t(dicts[i].dict_len) * value_size);
+        }
+        if (rows_knob && idx_max_bits <= pq2_ring_dict_max_bits() && dict_max_bytes <= pq2_ring_nullable_max_dict_bytes()) {
+            const uint64_t step = pq2_rowdir_step();
+            uint64_t dir_words = 0;
+            std::vector<uint64_t> dir_at(n_pages);
+            for (uint64_t i = 0; i < n_pages; ++i) {
+                dir_at[i] = dir_words;
+                dir_words += idx_descs[i].num_values / step + 3;  // (a tile's first span asks for three entries)
+            }
+            if ((st = reserve(ctx, ctx->d_rowdir, dir_words * sizeof(uint32_t)))) return st;
+            PQ2_HIP(ctx, hipEventRecord(ctx->bits_fork, stream));
+            PQ2_HIP(ctx, hipStreamWaitEvent(lane->lane_stream, ctx->bits_fork, 0));
+            st = pq2_decode_validity_bitmap_batch_device(lane, d_in, in_bytes, levels.data(), n_pages, lane->d_out.ptr,
+                                                         std::max<uint64_t>(bitmap_bytes, 4), nullptr, nullptr, nullptr,
+                                                         lane->lane_stream);
+            if (st != PQ2_OK) return fail(ctx, st, pq2_last_error(lane));
+            // one block: the GatherPage records ring_kernel takes the dictionaries from, then the RingNullable records
+            const size_t dict_recs = n_pages * sizeof(GatherPage);
+            const size_t bytes = dict_recs + n_pages * sizeof(RingNullable);
+            if ((st = stage_block(ctx, bytes, bytes))) return st;
+            GatherPage *g = static_cast<GatherPage *>(ctx->h_gather);
+            RingNullable *nl = reinterpret_cast<RingNullable *>(static_cast<uint8_t *>(ctx->h_gather) + dict_recs);
+            for (uint64_t i = 0; i < n_pages; ++i) {
+                const bool skip = lane->host_status[i] != PQ2_OK;  // (its rows are left alone, as on the other paths)
+                if (skip) indices[i].num_values = 0;
+                g[i].idx_addr = 0;
+                g[i].out_addr = reinterpret_cast<uint64_t>(d_out) + def_descs[i].out_off * value_size;
+                g[i].dict_addr = reinterpret_cast<uint64_t>(d_dict) + dicts[i].dict_off;
+                g[i].dict_len = dicts[i].dict_len;
+                g[i].num_values = static_cast<uint32_t>(indices[i].num_values);
+                g[i].first_tile = 0;
+                g[i].reserved = 0;
+                nl[i].bitmap_addr = reinterpret_cast<uint64_t>(lane->d_out.ptr) + levels[i].out_off;
+                nl[i].validity_addr = reinterpret_cast<uint64_t>(d_validity) + def_descs[i].out_off;
+                nl[i].out_addr = g[i].out_addr;
+                nl[i].rowdir_addr = reinterpret_cast<uint64_t>(ctx->d_rowdir.ptr) + dir_at[i] * sizeof(uint32_t);
+                nl[i].rows = skip ? 0u : static_cast<uint32_t>(def_descs[i].num_values);
+                nl[i].idx_values = static_cast<uint32_t>(indices[i].num_values);
+            }
+            if ((st = upload_block(ctx, bytes, lane->lane_stream))) return st;
+            const uint8_t *const d_nulls = static_cast<const uint8_t *>(ctx->d_gather.ptr) + dict_recs;
+            PQ2_HIP(ctx, pq2_launch_rowdir(d_nulls, static_cast<uint32_t>(n_pages), lane->lane_stream));
+            PQ2_HIP(ctx, hipEventRecord(ctx->bits_joined, lane->lane_stream));
+            PQ2_HIP(ctx, hipStreamWaitEvent(stream, ctx->bits_joined, 0));
+            FusedDict fd{ctx->d_gather.ptr, value_size / 4, static_cast<uint32_t>(dict_max_bytes)};
+            fd.d_nulls = d_nulls;
+            // (the descriptors' output offsets only have to be consistent: the kernel writes through the records above)
+            if ((st = enqueue_batch(ctx, d_in, in_bytes, indices.data(), n_pages, static_cast<uint32_t *>(d_out),
+                                    std::max<uint64_t>(idx_values, 1), stream, nullptr, 0, nullptr, &fd)))
+                return st;
+            PQ2_HIP(ctx, pq2_launch_nullable_status(static_cast<int32_t *>(ctx->d_status.ptr),
+                                                    static_cast<const int32_t *>(lane->d_status.ptr),
+                                                    static_cast<uint32_t>(n_pages), stream));
+            for (uint64_t i = 0; i < n_pages; ++i)
+                if (lane->host_status[i] != PQ2_OK) ctx->host_status[i] = lane->host_status[i];
+            ctx->last_schedule = "ring_kernel+bitmap (levels), ring_kernel+dictionary+rows (indices)";
+            if (status) return fetch_status(ctx, status, n_pages);
+            return PQ2_OK;
+        }
         // (optional_bits_kernel reads 16 bytes at a time from any index of a page on: 12 bytes behind the last page's)
         if ((st = reserve(ctx, ctx->d_indices, std::max<uint64_t>(idx_values, 1) * sizeof(uint32_t) + 16))) return st;
         // The index streams first: where this context looks at the headers before it settles on a schedule, that look

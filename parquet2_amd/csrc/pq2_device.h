@@ -98,6 +98,19 @@ constexpr uint32_t kRemMask = 0x7fffffffu;
 
 enum RunKind : uint32_t { kBitpacked = 0, kRle = 1, kEnd = 2, kPanic = 3 };
 
+// What ring_kernel<., kWords, true> needs of a flat nullable dictionary page beside its PageDev and RingDict: the
+// page's validity bitmap (row r at bit r % 32 of word r / 32, bits behind the page's rows 0), where its rows go, and
+// the row directory rowdir_kernel makes of the bitmap: entry m >= 1 is the row of the page's valid row number
+// kRowDirStep * m (counted from 0), or `rows` if the page has no more valid rows; entry 0 is 0.
+struct RingNullable {  // must match the host's
+    uint64_t bitmap_addr;    // 4-byte aligned
+    uint64_t validity_addr;  // one byte per row
+    uint64_t out_addr;       // kWords dwords per row
+    uint64_t rowdir_addr;    // idx_values / kRowDirStep + 3 words
+    uint32_t rows, idx_values;
+};
+constexpr uint32_t kRowDirStep = 2048;  // = the values of a span of ring_kernel
+
 // A nullable dictionary page after its two streams are decoded (optional_kernel, optional_bits_kernel).
 struct OptionalPage {  // must match the host's
     uint64_t level_addr;  // decoded levels: u32, one per row, 16-byte aligned; or the validity bitmap, row r at bit r % 32 of word r / 32

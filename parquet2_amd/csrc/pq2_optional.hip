@@ -184,6 +184,67 @@ __global__ __launch_bounds__(256) void optional_bits_kernel(const OptionalPage *
     }
 }
 
+// ---------------------------------------------------------------------------
+// rowdir_kernel: the row directories of flat nullable pages (RingNullable, pq2_device.h): for every page, the row of
+// its valid row number kRowDirStep * m for m = 1, 2, ... -- what an expanding wave of ring_kernel<., ., true> needs to
+// know where the rows of its span of indices begin and end.  One workgroup per page walks the page's validity bitmap
+// 1024 words at a time (four words per thread), carrying the count of valid rows.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rowdir_kernel(const RingNullable *__restrict__ nulls, uint32_t n_pages) {
+    __shared__ uint32_t wave_total[2][4];
+    const uint32_t page = blockIdx.x;
+    if (page >= n_pages) return;
+    const RingNullable nl = nulls[page];
+    uint32_t *const dir = (uint32_t *)nl.rowdir_addr;
+    const uint32_t n_spans = (nl.idx_values + kRowDirStep - 1u) / kRowDirStep;  // entries 0 .. n_spans are written
+    const uint32_t n_words = (nl.rows + 31u) >> 5;
+    const __amdgpu_buffer_rsrc_t bits = make_rsrc(nl.bitmap_addr, n_words * 4u);
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    uint32_t carry = 0, flip = 0;
+    for (uint32_t w0 = 0; w0 < n_words; w0 += 1024u, flip ^= 1u) {
+        const uint32_t wi = w0 + 4u * threadIdx.x;
+        const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(bits, wi * 4u, 0, 0);  // (behind the bitmap: 0)
+        const uint32_t word[4] = {x.x, x.y, x.z, x.w};
+        uint32_t pc[4], s = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 4u; ++i) pc[i] = (uint32_t)__builtin_popcount(word[i]), s += pc[i];
+        const uint32_t incl = wave_inclusive_sum(s);
+        if (lane == 63u) wave_total[flip][wave] = incl;
+        __syncthreads();  // (the other buffer is written in the next step, this one again only after that step's barrier)
+        uint32_t before = carry, all = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) {
+            const uint32_t t = wave_total[flip][k];
+            before += k < wave ? t : 0u;
+            all += t;
+        }
+        uint32_t c = before + incl - s;  // valid rows before this thread's first word
+#pragma unroll
+        for (uint32_t i = 0; i < 4u; ++i) {
+            // the step of the directory that lies in this word, if one does: the smallest m with kRowDirStep * m >= c
+            const uint32_t m = (c + kRowDirStep - 1u) / kRowDirStep;
+            if (pc[i] != 0u && m >= 1u && m <= n_spans && m * kRowDirStep < c + pc[i]) {
+                uint32_t left = word[i];
+                for (uint32_t t = m * kRowDirStep - c; t != 0u; --t) left &= left - 1u;  // (fewer than 32 times)
+                dir[m] = (wi + i) * 32u + (uint32_t)__builtin_ctz(left);
+            }
+            c += pc[i];
+        }
+        carry += all;
+    }
+    // the steps the page's valid rows do not reach
+    for (uint32_t m = (carry + kRowDirStep - 1u) / kRowDirStep + threadIdx.x; m <= n_spans; m += 256u)
+        if (m >= 1u) dir[m] = nl.rows;
+    if (threadIdx.x == 0) dir[0] = 0u;
+}
+
+// status[i] = the level stream's where it has one, else what ring_kernel left of the index stream and the lookup
+__global__ __launch_bounds__(256) void nullable_status_kernel(int32_t *__restrict__ status, const int32_t *__restrict__ level_status,
+                                                              uint32_t n_pages) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n_pages && level_status[i] != 0) status[i] = level_status[i];
+}
+
 template <int kWords>
 static void launch_optional_bits(const OptionalPage *p, uint32_t n_pages, int32_t *status, const int32_t *level_status,
                                  uint32_t dict_bytes, hipStream_t stream) {
@@ -211,5 +272,18 @@ extern "C" hipError_t pq2_launch_optional_bits(const void *pages, uint32_t n_pag
         pq2::launch_optional_bits<2>(p, n_pages, status, level_status, db, stream);
     else
         pq2::launch_optional_bits<3>(p, n_pages, status, level_status, db, stream);
+    return hipGetLastError();
+}
+
+// `nulls`: one pq2::RingNullable per page (device), the pages' bitmaps complete on `stream`.
+extern "C" hipError_t pq2_launch_rowdir(const void *nulls, uint32_t n_pages, hipStream_t stream) {
+    if (n_pages == 0) return hipSuccess;
+    hipLaunchKernelGGL(pq2::rowdir_kernel, dim3(n_pages), dim3(256), 0, stream, (const pq2::RingNullable *)nulls, n_pages);
+    return hipGetLastError();
+}
+extern "C" uint32_t pq2_rowdir_step() { return pq2::kRowDirStep; }
+extern "C" hipError_t pq2_launch_nullable_status(int32_t *status, const int32_t *level_status, uint32_t n_pages, hipStream_t stream) {
+    if (n_pages == 0) return hipSuccess;
+    hipLaunchKernelGGL(pq2::nullable_status_kernel, dim3((n_pages + 255u) / 256u), dim3(256), 0, stream, status, level_status, n_pages);
     return hipGetLastError();
 }

@@ -811,6 +811,114 @@ struct DictSink {
     }
 };
 
+// StageSink keeps the span's values -- dictionary indices of at most 16 bits -- in LDS, position p at stage[p]:
+// for pages whose rows are not their values' positions (flat nullable columns, ring_place_span below).
+struct StageSink {
+    uint16_t *stage;  // LDS: kRowDirStep entries
+    __device__ __forceinline__ uint32_t mis() const { return 0u; }
+    __device__ __forceinline__ void put4(const u32x4 j, const int32_t p) {
+        *(uint2 *)&stage[p] = make_uint2((j.x & 0xffffu) | (j.y << 16), (j.z & 0xffffu) | (j.w << 16));
+    }
+    __device__ __forceinline__ void put1(const uint32_t j, const int32_t p) { stage[p] = (uint16_t)j; }
+};
+
+// The rows [row_lo, row_hi) of a flat nullable dictionary page, which hold the page's valid rows number
+// first .. first + span_n - 1 (their indices lie in `stage`) and no others that have an index: row r is valid where
+// its bit is set, the k-th valid row takes the dictionary value of the k-th index, a valid row behind the last index
+// is null (deserialize_levels, tests/it/read/utils.rs:52-66, over an OptionalDictionary page,
+// tests/it/read/primitive.rs:104-110).  The wave takes 256 rows a step, four consecutive rows per lane at a multiple
+// of four (whole quads are stored with one instruction where the page's values and validity bytes are aligned); a
+// prefix sum over the lanes' valid rows says which index a row takes.  Reads go through buffer descriptors: none is
+// under a branch, and the bitmap's words come through LDS (`wbuf`: kRingPlaceWords words, which the caller has
+// filled from the word of row_lo on if `preloaded` -- asked for before the span was expanded, so that nobody waits).
+constexpr uint32_t kRingPlaceWords = 96;   // the rows of 3072 bits (with these, three workgroups fit a compute unit's LDS beside dictionaries of 16 KiB)
+constexpr uint32_t kRingStageBytes = kRowDirStep * 2u + kRingPlaceWords * 4u;  // LDS per expanding wave (kNullable)
+template <int kWords>
+__device__ __forceinline__ void ring_place_span(const RingNullable &nl, const uint16_t *stage, uint32_t *wbuf, bool preloaded,
+                                                const uint32_t *dict, const uint32_t dict_len, const uint32_t span_n,
+                                                const uint32_t row_lo, const uint32_t row_hi, bool &bad, const uint32_t lane) {
+    if (row_lo >= row_hi) return;
+    const __amdgpu_buffer_rsrc_t bits = make_rsrc(nl.bitmap_addr, ((nl.rows + 31u) >> 5) * 4u);
+    out_u32 *const out = (out_u32 *)nl.out_addr;
+    __attribute__((address_space(1))) uint8_t *const validity = (__attribute__((address_space(1))) uint8_t *)nl.validity_addr;
+    const bool aligned = ((nl.out_addr & 15u) | (nl.validity_addr & 3u)) == 0u;
+    uint32_t used = 0;                // valid rows before this step
+    uint32_t chunk_w = row_lo >> 5;   // wbuf holds the bitmap's words chunk_w .. chunk_w + kRingPlaceWords - 1
+    for (uint32_t r_base = row_lo & ~3u; r_base < row_hi; r_base += 256u) {
+        if (!preloaded || ((r_base + 255u) >> 5) >= chunk_w + kRingPlaceWords) {
+            // (a span whose valid rows are spread over more than 3000 rows: the next words, one trip to memory)
+            chunk_w = r_base >> 5;
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t x0 = __builtin_amdgcn_raw_buffer_load_b32(bits, (chunk_w + lane) * 4u, 0, 0);
+            const uint32_t x1 = __builtin_amdgcn_raw_buffer_load_b32(bits, (chunk_w + 64u + lane) * 4u, 0, 0);
+            wbuf[lane] = x0;
+            if (lane + 64u < kRingPlaceWords) wbuf[lane + 64u] = x1;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            preloaded = true;
+        }
+        const uint32_t r0 = r_base + 4u * lane;
+        // the validity bits of rows r0 .. r0 + 3, those outside [row_lo, row_hi) cleared
+        // (rows are fewer than 2^31: the differences are taken as signed numbers and clamped to 0 .. 4)
+        const uint32_t below = (uint32_t)max(0, min((int32_t)(row_lo - r0), 4));
+        const uint32_t upto = (uint32_t)max(0, min((int32_t)(row_hi - r0), 4));
+        const uint32_t inside = (15u << below) & ((1u << upto) - 1u);  // bit k: row r0 + k is one of [row_lo, row_hi)
+        const uint32_t nib = (wbuf[min((r0 >> 5) - chunk_w, kRingPlaceWords - 1u)] >> (r0 & 31u)) & inside;
+        const uint32_t c = (uint32_t)__builtin_popcount(nib);
+        const uint32_t incl = wave_inclusive_sum(c);
+        uint32_t rl = used + incl - c;
+        used += __builtin_amdgcn_readlane(incl, 63);
+        // the four rows' indices, then their values: every read is asked for before the first is waited for
+        uint32_t rank[4], j[4], at[4], pres = 0;
+        rank[0] = rl;
+#pragma unroll
+        for (uint32_t k = 1; k < 4u; ++k) rank[k] = rank[k - 1u] + ((nib >> (k - 1u)) & 1u);
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) j[k] = stage[rank[k] & (kRowDirStep - 1u)];
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) {
+            const bool present = ((nib >> k) & 1u) != 0u && rank[k] < span_n;
+            const bool ok = j[k] < dict_len;
+            bad |= present && !ok;
+            pres |= (present ? 1u : 0u) << k;
+            at[k] = present && ok ? j[k] * (uint32_t)kWords : 0xffffffffu;
+        }
+        uint32_t val[4][kWords];
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k)
+#pragma unroll
+            for (int c2 = 0; c2 < kWords; ++c2) val[k][c2] = dict[at[k] == 0xffffffffu ? 0u : at[k] + c2];  // (entry 0: any LDS word)
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k)
+#pragma unroll
+            for (int c2 = 0; c2 < kWords; ++c2) val[k][c2] = at[k] == 0xffffffffu ? 0u : val[k][c2];
+        if (aligned && inside == 15u) {
+            uint32_t flat[4 * kWords];
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k)
+#pragma unroll
+                for (int c2 = 0; c2 < kWords; ++c2) flat[k * kWords + c2] = val[k][c2];
+#pragma unroll
+            for (int c2 = 0; c2 < kWords; ++c2) {
+                const u32x4 o = {flat[4 * c2], flat[4 * c2 + 1], flat[4 * c2 + 2], flat[4 * c2 + 3]};
+                __builtin_nontemporal_store(o, (out_u32x4 *)out + (size_t)(r0 >> 2) * kWords + c2);
+            }
+            // bits 0..3 -> bytes 0..3
+            *(__attribute__((address_space(1))) uint32_t *)(validity + r0) = (pres * 0x00204081u) & 0x01010101u;
+        } else {
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k) {
+                const uint32_t r = r0 + k;
+                if ((inside >> k) & 1u) {
+#pragma unroll
+                    for (int c2 = 0; c2 < kWords; ++c2) out[(size_t)r * kWords + c2] = val[k][c2];
+                    validity[r] = (uint8_t)((pres >> k) & 1u);
+                }
+            }
+        }
+    }
+}
+
 // `count` positions from 0 on, all of them `value` (a page of width 0, or one without a stream).
 template <typename Sink>
 __device__ __forceinline__ void ring_fill_span(Sink &sink, const uint32_t value, const uint32_t count, const uint32_t lane) {
@@ -1661,6 +1769,7 @@ struct RingDict {
 };
 constexpr uint32_t kRingFlagWholeTileSpans = 1u;  // ring_kernel's `flags`: a batch of nothing but levels (see kRingWholeTileBits)
 constexpr uint32_t kRingFlagTurns = 2u;           // ... the workgroups of a compute unit take turns in priority
+constexpr uint32_t kRingFlagStageShift = 8;       // ... from this bit on: where in LDS the expanding waves' StageSinks begin (kNullable)
 constexpr uint32_t kRingTurnsMaxBits = 20;        // the widest page of a batch that is given turns
 constexpr uint32_t kRingTurnsMinPages = 1025;     // ... and its fewest pages: one more than 256 compute units hold workgroups
 constexpr uint32_t kRingDictMaxBits = 12;  // widest index the kernels with a dictionary are built for
@@ -1671,13 +1780,21 @@ constexpr uint32_t kRingDictMaxBits = 12;  // widest index the kernels with a di
 // one-bit definition levels and come out as validity bitmaps (ring_expand_span_bits), page p's at the 4-byte aligned
 // address PageDev::out_addr; bit_meta[2 p] receives the rows the page's stream holds and bit_meta[2 p + 1], which
 // must be 0 at the launch, the number of set bits.
-template <bool kWide, int kWords>
+//
+// kNullable (with kWords > 0): the pages are the index streams of flat nullable dictionary pages, and the values go
+// to the pages' ROWS: `nulls` has a RingNullable per page.  An expanding wave keeps the indices of a span in LDS
+// (StageSink; kRowDirStep two-byte entries per wave behind the dictionary), looks up in the page's row directory
+// which rows the span's valid rows lie in, and writes those rows, nulls included (ring_place_span): neither the
+// indices nor the levels ever lie in device memory, only the validity bitmap the levels were turned into before.
+template <bool kWide, int kWords, bool kNullable = false>
 __global__ __launch_bounds__(kRingThreads, PQ2_RING_MIN_WAVES) void ring_kernel(const PageDev *__restrict__ pages, uint32_t n_pages,
                                                        int32_t *__restrict__ status, uint32_t *__restrict__ cu_tickets,
                                                        uint32_t ring_bytes, const uint32_t *__restrict__ tile_mask,
                                                        const RingDict *__restrict__ dicts, uint32_t dict_at,
                                                        uint32_t flags, uint32_t epoch,
-                                                       uint32_t *__restrict__ bit_meta, const uint32_t *__restrict__ go) {
+                                                       uint32_t *__restrict__ bit_meta, const uint32_t *__restrict__ go,
+                                                       const RingNullable *__restrict__ nulls) {
+    static_assert(!kNullable || kWords > 0, "nullable pages are dictionary pages");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     // a launch that was enqueued before the batch's schedule was final (density_kernel, pq2_density.hip) and has
     // been told that the other schedule takes the batch: nothing is touched
@@ -1690,6 +1807,13 @@ __global__ __launch_bounds__(kRingThreads, PQ2_RING_MIN_WAVES) void ring_kernel(
     const PageDev pg = pages[page];
     const uint32_t n = pg.num_values;
     if (n == 0) {
+        if constexpr (kNullable) {  // no index: every row is null
+            const RingNullable nl = nulls[page];
+            bool bad = false;
+            if (wave == 0)
+                ring_place_span<kWords>(nl, (const uint16_t *)(lds + 1024), (uint32_t *)lds, false, (const uint32_t *)lds, 0u, 0u, 0u,
+                                        nl.rows, bad, lane);
+        }
         if (threadIdx.x == 0 && kWords <= 0) status[page] = 0;
         if (threadIdx.x == 0 && kWords < 0) bit_meta[2u * page] = 0u;
         return;
@@ -1786,6 +1910,7 @@ __global__ __launch_bounds__(kRingThreads, PQ2_RING_MIN_WAVES) void ring_kernel(
     constexpr uint32_t kGroup = kWide ? PQ2_RING_STEP_GROUP_WIDE : PQ2_RING_STEP_GROUP;
 
     const uint64_t clock_begin = PQ2_CLOCK();
+    uint32_t dir_rows[3] = {0u, 0u, 0u};  // (kNullable) the row directory's entries of the tile in hand
     for (uint32_t t = e; t < n_tiles;) {
         io.tile = t;
         io.need = kTileFresh;
@@ -1872,6 +1997,45 @@ __global__ __launch_bounds__(kRingThreads, PQ2_RING_MIN_WAVES) void ring_kernel(
                             }
                             break;
                     }
+                } else if constexpr (kNullable) {
+                    static_assert(kRingSpanBlocks * kBlockValues == kRowDirStep, "a span is a step of the row directory");
+                    const RingNullable nl = nulls[page];
+                    // The rows of the tile's spans: asked for at the tile's first span, so that only that one waits for
+                    // the directory; the bitmap's words from the span's first row on are asked for now and are there by
+                    // the time the span's indices are in LDS.
+                    typedef __attribute__((address_space(1))) const uint32_t gu32;
+                    if (i == 0) {
+                        gu32 *const dir = (gu32 *)nl.rowdir_addr + tile_first / kRowDirStep;
+                        dir_rows[0] = dir[0], dir_rows[1] = dir[1], dir_rows[2] = dir[2];
+                    }
+                    const bool last = span_first + span_n >= n;  // the rows behind the last index are the last span's too
+                    const uint32_t row_lo = __builtin_amdgcn_readfirstlane(i == 0 ? dir_rows[0] : dir_rows[1]);
+                    const uint32_t row_hi = last ? nl.rows : __builtin_amdgcn_readfirstlane(i == 0 ? dir_rows[1] : dir_rows[2]);
+                    const __amdgpu_buffer_rsrc_t bits = make_rsrc(nl.bitmap_addr, ((nl.rows + 31u) >> 5) * 4u);
+                    uint32_t x0 = __builtin_amdgcn_raw_buffer_load_b32(bits, ((row_lo >> 5) + lane) * 4u, 0, 0);
+                    uint32_t x1 = __builtin_amdgcn_raw_buffer_load_b32(bits, ((row_lo >> 5) + 64u + lane) * 4u, 0, 0);
+                    uint8_t *const mine = lds + (flags >> kRingFlagStageShift) + e * kRingStageBytes;
+                    uint16_t *const stage = (uint16_t *)mine;
+                    uint32_t *const wbuf = (uint32_t *)(mine + kRowDirStep * 2u);
+                    StageSink sink = {stage};
+                    static_assert(kRingDictMaxBits == 12, "the cases below");
+                    switch (w) {
+                        PQ2_W(1) PQ2_W(2) PQ2_W(3) PQ2_W(4) PQ2_W(5) PQ2_W(6) PQ2_W(7) PQ2_W(8)
+                        PQ2_W(9) PQ2_W(10) PQ2_W(11) PQ2_W(12)
+                        case 0:  // every index is 0
+                            ring_fill_span(sink, 0u, span_n, lane);
+                            break;
+                        default:  // the host does not send wider pages here
+                            io.abort_all(lane, 9);
+                            break;
+                    }
+                    if (io.aborted) return;
+                    wbuf[lane] = x0;
+                    if (lane + 64u < kRingPlaceWords) wbuf[lane + 64u] = x1;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    ring_place_span<kWords>(nl, stage, wbuf, true, dict_lds, dict_len, span_n, row_lo, row_hi, bad_index, lane);
+                    __builtin_amdgcn_wave_barrier();  // (the next span's indices go where these lay)
                 } else {
                     DictSink<kWords> sink = {(out_u32 *)value_addr + (size_t)span_first * kWords, dict_lds, dict_len, false};
                     static_assert(kRingDictMaxBits == 12, "the cases below");

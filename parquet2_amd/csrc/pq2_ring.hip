@@ -50,11 +50,11 @@ extern "C" hipError_t pq2_launch_ring(const void *pages, uint32_t n_pages, int32
         }
         hipLaunchKernelGGL((pq2::ring_kernel<true, 0>), dim3(n_pages), dim3(pq2::kRingThreads), lds_bytes, stream,
                            (const pq2::PageDev *)pages, n_pages, status, cu_tickets, ring_bytes, tile_mask,
-                           (const pq2::RingDict *)nullptr, 0u, flags, epoch, (uint32_t *)nullptr, go);
+                           (const pq2::RingDict *)nullptr, 0u, flags, epoch, (uint32_t *)nullptr, go, (const pq2::RingNullable *)nullptr);
     } else {
         hipLaunchKernelGGL((pq2::ring_kernel<false, 0>), dim3(n_pages), dim3(pq2::kRingThreads), lds_bytes, stream,
                            (const pq2::PageDev *)pages, n_pages, status, cu_tickets, ring_bytes, tile_mask,
-                           (const pq2::RingDict *)nullptr, 0u, flags, epoch, (uint32_t *)nullptr, go);
+                           (const pq2::RingDict *)nullptr, 0u, flags, epoch, (uint32_t *)nullptr, go, (const pq2::RingNullable *)nullptr);
     }
     return hipGetLastError();
 }
@@ -73,6 +73,6 @@ extern "C" hipError_t pq2_launch_ring_bits(const void *pages, uint32_t n_pages, 
     }
     hipLaunchKernelGGL((pq2::ring_kernel<false, -1>), dim3(n_pages), dim3(pq2::kRingThreads), pq2::ring_lds_bytes(ring_bytes),
                        stream, (const pq2::PageDev *)pages, n_pages, status, cu_tickets, ring_bytes,
-                       (const uint32_t *)nullptr, (const pq2::RingDict *)nullptr, 0u, 0u, epoch, bit_meta, (const uint32_t *)nullptr);
+                       (const uint32_t *)nullptr, (const pq2::RingDict *)nullptr, 0u, 0u, epoch, bit_meta, (const uint32_t *)nullptr, (const pq2::RingNullable *)nullptr);
     return hipGetLastError();
 }

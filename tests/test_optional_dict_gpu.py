@@ -206,13 +206,16 @@ def test_statuses(ctx, oracle):
     assert (validity[o:o + rows] == short_levels).all() and (got[o:o + few, 0] == table[3, 0]).all()
 
 
-@pytest.mark.parametrize("value_size,idx_bits", [(4, 8), (8, 9), (12, 12)])
+@pytest.mark.parametrize("value_size,idx_bits", [(4, 8), (8, 9), (4, 12), (12, 12)])
 def test_flat_nullable_batches_read_their_levels_as_bitmaps(oracle, value_size, idx_bits):
     """From 256 pages on, a batch of flat nullable pages (every maximum level 1) has its level streams turned into
-    validity bitmaps and optional_bits_kernel reads those: same values, validity and statuses.  Pages of one row to
-    several steps of 4096 rows, outputs that are not aligned, dictionaries that fit the workgroups' LDS (8 and 9 bits)
-    and one that does not (12 bits x 12 bytes), index streams shorter than the valid rows, and the failures: an
-    index stream and a level stream the reference panics on, a dictionary that misses a consumed index."""
+    validity bitmaps: same values, validity and statuses.  Where the dictionaries have at most 16 KiB (the first three
+    cases) the index streams are decoded by ring_kernel straight into the pages' rows (no index ever lies in device
+    memory); beyond (12 bits x 12 bytes) the indices are written and optional_bits_kernel places them.  Pages of one
+    row to several spans of 2048 valid rows, outputs that are not aligned, gaps of up to 300 rows between the pages
+    that must stay untouched, pages with long stretches of nulls, index streams shorter than the valid rows, and the
+    failures: an index stream and a level stream the reference panics on, a dictionary that misses a consumed
+    index."""
     from parquet2_amd import Context
 
     rng = np.random.default_rng(1000 + value_size)
@@ -237,13 +240,14 @@ def test_flat_nullable_batches_read_their_levels_as_bitmaps(oracle, value_size, 
         elif p == 22 and n_valid > 0:
             dict_len, st = int(idx[:n_valid].max()), OUT_OF_SPEC
         args = (def_stream, 1, rows, idx_stream, 12 if p == 20 else idx_bits, idx_values)
-        b.add(*args, (0, dict_len, 0), gap=p % 3)
+        b.add(*args, (0, dict_len, 0), gap=(p % 3) * 150 + p % 2)
         pages.append((args, dict_len))
         want_status.append(st)
     ctx = Context(0)
     try:
         got, validity, status = b.run(ctx, table.view(np.uint8).reshape(-1), value_size)
         assert "bitmap" in ctx.last_schedule(), ctx.last_schedule()
+        assert ("rows" in ctx.last_schedule()) == (len(table) * value_size <= 16384), ctx.last_schedule()
     finally:
         ctx.close()
     assert list(status) == want_status

@@ -10,7 +10,7 @@ from parquet2_amd import DICT_REF_DTYPE, PAGE_DESC_DTYPE, Context, synth
 pages_n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 rows = int(sys.argv[2]) if len(sys.argv) > 2 else 1 << 18
 value_size = int(sys.argv[3]) if len(sys.argv) > 3 else 4
-steps = 10
+steps = int(sys.argv[4]) if len(sys.argv) > 4 else 10
 dev = torch.device("cuda", 0)
 distinct = [(synth.def_levels_page(synth.seed_for(3, p), rows), synth.dict_page(synth.seed_for(2, p), rows, 12))
             for p in range(8)]
@@ -53,15 +53,20 @@ lv, ix = distinct[3][0][1], distinct[3][1][1]
 valid = lv == 1
 exp = torch.zeros(rows, words, dtype=torch.int32)
 exp[torch.from_numpy(valid)] = table.view(4096, words).cpu()[torch.from_numpy(ix[:int(valid.sum())].astype(np.int64))]
-assert torch.equal(d_out.view(pages_n, rows, words)[3].cpu(), exp)
+assert os.environ.get("PQ2_BENCH_NO_CHECK") or torch.equal(d_out.view(pages_n, rows, words)[3].cpu(), exp)  # (diagnostic builds write nothing)
 for _ in range(2):
     step()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
+host = []
 for _ in range(steps):
+    h0 = time.perf_counter()
     step()
+    host.append(time.perf_counter() - h0)
 torch.cuda.synchronize()
 el = (time.perf_counter() - t0) / steps
+if os.environ.get("PQ2_BENCH_HOST"):
+    print("host ms per call:", [round(h * 1e3, 2) for h in host], file=sys.stderr)
 print(json.dumps({"pages": pages_n, "rows_per_page": rows, "value_size": value_size, "ms_per_step": round(el * 1e3, 3),
                   "rows_per_second_G": round(pages_n * rows / el / 1e9, 2),
                   "value_plus_validity_GBps": round(pages_n * rows * (value_size + 1) / el / 1e9, 1)}))

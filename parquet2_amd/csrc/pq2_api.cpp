@@ -60,7 +60,7 @@ hipError_t pq2_launch_ring_bits(const void *pages, uint32_t n_pages, int32_t *st
                                 uint32_t *bit_meta, hipStream_t stream);  // pq2_ring.hip
 hipError_t pq2_launch_ring_dict(const void *pages, uint32_t n_pages, int32_t *status, uint32_t *cu_tickets,
                                 uint32_t epoch, const uint32_t *tile_mask, const void *dicts, uint32_t value_words, uint32_t max_dict_bytes,
-                                const void *nulls, hipStream_t stream);
+                                const void *nulls, const uint32_t *go, hipStream_t stream);
 uint32_t pq2_ring_nullable_max_dict_bytes();
 hipError_t pq2_launch_rowdir(const void *nulls, uint32_t n_pages, hipStream_t stream);  // pq2_optional.hip
 uint32_t pq2_rowdir_step();
@@ -205,6 +205,7 @@ struct pq2_ctx {
     // pq2_decode_dict_batch_device: the decoded indices, and the per-page gather descriptors (page-locked + device)
     DevBuf d_indices, d_gather, d_seg_valid;
     DevBuf d_bit_meta;  // pq2_decode_validity_bitmap_batch_device: rows and set bits of every page
+    bool fused_declined = false;  // enqueue_batch: the density probe sent a batch with the lookup inside ring_kernel elsewhere
     DevBuf d_rowdir;    // pq2_decode_optional_dict_batch_device: the row directories of flat nullable pages (rowdir_kernel)
     // density_kernel (pq2_density.hip): its two counters and the verdict word on the device, the verdict as the host
     // reads it (page-locked, written by the device), the event behind the kernel, a count of its launches
@@ -607,8 +608,10 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
     // time; the host reads the verdict when the probe has run and, on a "no", enqueues the scout kernels instead.
     uint32_t *d_go = nullptr;
     ctx->last_density_headers = 0;
-    const bool probe = ring && !fused && !bits && !front && !mask && ctx->mode == pq2_ctx::kAuto && ctx->probe_density &&
-                       n_pages >= kScoutMaxPages && n_pages <= 4 * kRingSlots;
+    // (with the dictionary lookup inside ring_kernel as well: on a "no" the caller takes the indices through memory)
+    const bool probe = ring && !(fused && fused->d_nulls) && !bits && !front && !mask && ctx->mode == pq2_ctx::kAuto &&
+                       ctx->probe_density && n_pages >= kScoutMaxPages && n_pages <= 4 * kRingSlots;
+    ctx->fused_declined = false;
     if (probe) {
         // (device: the verdict word, then two words per sampled page of what the pages showed)
         if ((st = reserve(ctx, ctx->d_density, 16 + 512 * 8))) return st;
@@ -624,7 +627,10 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
         const BatchBytes bb = batch_bytes(descs, n_pages);
         // (microseconds, as in auto_takes_scout; a header costs a walking wave 0.1 us, and up to twice that where four
         // walks of dense headers share a compute unit)
-        const double scout_us = 40.0 + bb.in_total * 2.8e-6 + bb.out_total / 3.5e6;
+        double scout_us = 40.0 + bb.in_total * 2.8e-6 + bb.out_total / 3.5e6;
+        // (a batch with the lookup inside ring_kernel: the other way has gather_kernel behind the scout kernels, which
+        // reads the indices and writes the values at about 4 TB/s)
+        if (fused) scout_us += 20.0 + bb.out_total * (1.0 + fused->value_words) / 4.0e6;
         const double turns = double((n_pages + kRingSlots - 1) / kRingSlots);
         const double per_header_us = n_pages <= kRingSlots / 4 ? 0.1 : 0.16;
         ++ctx->density_seq;
@@ -651,7 +657,7 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
                  if (fused)
                      return pq2_launch_ring_dict(d_pages, static_cast<uint32_t>(n_pages), d_status, ring_tickets,
                                                  ctx->ring_epoch++, d_tile_mask, fused->d_dicts, fused->value_words,
-                                                 fused->max_dict_bytes, fused->d_nulls, stream);
+                                                 fused->max_dict_bytes, fused->d_nulls, d_go, stream);
                  if (bits)
                      return pq2_launch_ring_bits(d_pages, static_cast<uint32_t>(n_pages), d_status, ring_tickets,
                                                  ctx->ring_epoch++, bits->d_meta, stream);
@@ -674,6 +680,10 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
             // the ring_kernel launch above finds the same verdict and touches nothing: the scout kernels take the batch
             // (what was stamped for it counts as time of the header walk)
             if (ctx->profiling && !ctx->stamps.empty()) ctx->stamps.back().expand = false;
+            if (fused) {  // the caller decodes to indices (through the scout kernels) and looks them up afterwards
+                ctx->fused_declined = true;
+                return PQ2_OK;
+            }
             const pq2_ctx::Mode was = ctx->mode;
             const uint32_t expected = ctx->last_density_headers;
             ctx->mode = pq2_ctx::kScout;
@@ -1000,6 +1010,38 @@ int32_t pq2_decode_dict_batch_device(pq2_ctx *ctx, const void *d_in, uint64_t in
             if ((st = enqueue_batch(ctx, d_in, in_bytes, descs, n_pages, static_cast<uint32_t *>(d_out), out_values, stream,
                                     nullptr, 0, nullptr, &fd)))
                 return st;
+            if (ctx->fused_declined) {
+                // The pages' headers are too dense for one walking wave per page (density_kernel): the scout kernels
+                // decode the batch into indices and gather_kernel looks them up, as for a batch of few pages.
+                if ((st = reserve(ctx, ctx->d_indices, std::max<uint64_t>(out_values, 1) * sizeof(uint32_t)))) return st;
+                d_idx = static_cast<uint32_t *>(ctx->d_indices.ptr);
+                const pq2_ctx::Mode was = ctx->mode;
+                const uint32_t expected = ctx->last_density_headers;
+                ctx->mode = pq2_ctx::kScout;
+                st = enqueue_batch(ctx, d_in, in_bytes, descs, n_pages, d_idx, out_values, stream);
+                ctx->mode = was;
+                ctx->last_density_headers = expected;
+                if (st) return st;
+                if ((st = stage_block(ctx, bytes, bytes))) return st;
+                g = static_cast<GatherPage *>(ctx->h_gather);
+                tiles = 0;
+                for (uint64_t i = 0; i < n_pages; ++i) {
+                    const pq2_page_desc &d = descs[i];
+                    g[i].idx_addr = reinterpret_cast<uint64_t>(d_idx) + d.out_off * sizeof(uint32_t);
+                    g[i].out_addr = reinterpret_cast<uint64_t>(d_out) + d.out_off * value_size;
+                    g[i].dict_addr = reinterpret_cast<uint64_t>(d_dict) + dicts[i].dict_off;
+                    g[i].dict_len = dicts[i].dict_len;
+                    g[i].num_values = ctx->host_status[i] == PQ2_OK ? static_cast<uint32_t>(d.num_values) : 0u;
+                    g[i].first_tile = static_cast<uint32_t>(tiles);
+                    g[i].reserved = 0;
+                    tiles += (uint64_t(g[i].num_values) + kGatherTileValues - 1) / kGatherTileValues;
+                }
+                if ((st = upload_block(ctx, bytes, stream))) return st;
+                PQ2_HIP(ctx, pq2_launch_gather(ctx->d_gather.ptr, static_cast<uint32_t>(n_pages), static_cast<uint32_t>(tiles),
+                                               value_size / 4, max_dict_bytes, static_cast<int32_t *>(ctx->d_status.ptr),
+                                               stream));
+                ctx->last_schedule = "scout+expand_kernel+gather_kernel";
+            }
         } else {
             PQ2_HIP(ctx, pq2_launch_gather(ctx->d_gather.ptr, static_cast<uint32_t>(n_pages), static_cast<uint32_t>(tiles),
                                            value_size / 4, max_dict_bytes, static_cast<int32_t *>(ctx->d_status.ptr),

@@ -12,13 +12,13 @@ extern "C" uint32_t pq2_ring_dict_max_bytes() { return 49152u; }
 
 // `dicts`: one pq2::RingDict per page (device); `value_words`: 1, 2 or 3; `max_dict_bytes`: of the largest
 // dictionary of the batch (at most pq2_ring_dict_max_bytes()); every page is at most pq2_ring_dict_max_bits() wide.
-// The statuses must have been cleared on `stream`.
+// The statuses must have been cleared on `stream`.  `go`: as pq2_launch_ring's.
 // `nulls`: null, or one pq2::RingNullable per page: the pages are the index streams of flat nullable pages, and the
 // values go to the pages' rows (ring_kernel<., ., true>; dictionaries of at most pq2_ring_nullable_max_dict_bytes()).
 extern "C" uint32_t pq2_ring_nullable_max_dict_bytes() { return 16384u; }  // (beyond: one workgroup per compute unit)
 extern "C" hipError_t pq2_launch_ring_dict(const void *pages, uint32_t n_pages, int32_t *status, uint32_t *cu_tickets,
                                            uint32_t epoch, const uint32_t *tile_mask, const void *dicts, uint32_t value_words,
-                                           uint32_t max_dict_bytes, const void *nulls, hipStream_t stream) {
+                                           uint32_t max_dict_bytes, const void *nulls, const uint32_t *go, hipStream_t stream) {
     if (n_pages == 0) return hipSuccess;
     const uint32_t dict_bytes = (max_dict_bytes + 15u) & ~15u;
     // (nullable pages: every expanding wave keeps a span's indices in LDS, two bytes each, and 4096 bits of the bitmap)
@@ -52,7 +52,7 @@ extern "C" hipError_t pq2_launch_ring_dict(const void *pages, uint32_t n_pages, 
     hipLaunchKernelGGL((pq2::ring_kernel<false, WORDS, NULLABLE>), dim3(n_pages), dim3(pq2::kRingThreads), lds_bytes, \
                        stream, (const pq2::PageDev *)pages, n_pages, status, cu_tickets, ring_bytes, tile_mask,       \
                        (const pq2::RingDict *)dicts, dict_at, flags, epoch, (uint32_t *)nullptr,                      \
-                       (const uint32_t *)nullptr, (const pq2::RingNullable *)nulls)
+                       go, (const pq2::RingNullable *)nulls)
 #define PQ2_LAUNCH(WORDS)                \
     if (nulls) {                         \
         PQ2_LAUNCH_AS(WORDS, true);      \

@@ -192,3 +192,37 @@ def test_bad_arguments(ctx):
         with pytest.raises(InvalidParameter):
             ctx.decode_dict_batch_device(d.data_ptr(), 64, descs, d.data_ptr(), 64,
                                          np.array([ref], dtype=DICT_REF_DTYPE), value_size, d.data_ptr(), 4)
+
+
+def test_dense_headers_send_a_dictionary_batch_round_the_lookup_inside(oracle):
+    """200 dictionary pages of short runs (a header per six values): the default schedule looks at the headers, does not
+    give the batch to ring_kernel with the lookup inside, and decodes to indices through the scout kernels with
+    gather_kernel behind; 200 pages of long runs stay with the lookup inside.  Same values either way."""
+    from parquet2_amd import Context
+
+    rng = np.random.default_rng(17)
+    n, w = 60000, 8
+    table = rng.integers(0, 1 << 32, size=(1 << w, 1), dtype=np.uint64).astype(np.uint32)
+    ctx = Context(0)
+    try:
+        for kind in ("short", "long"):
+            batch = synth.PageBatch()
+            want = []
+            for p in range(200):
+                stream, vals = (synth.adversarial(synth.seed_for(4, 300 + p), n, w) if kind == "short"
+                                else synth.dict_page(synth.seed_for(2, 300 + p), n, w))
+                batch.add(stream, w, n)
+                st, idx = oracle.hybrid_rle_decode(stream, w, n)
+                assert st == OK and np.array_equal(idx, vals)
+                want.append(table[idx, 0])
+            data, descs, out_values = batch.finish()
+            refs = np.zeros(200, dtype=DICT_REF_DTYPE)
+            refs["dict_len"] = len(table)
+            got, status = run(ctx, data, descs, out_values, table.view(np.uint8).reshape(-1), refs, 4)
+            assert (status == OK).all()
+            assert ("gather_kernel" in ctx.last_schedule()) == (kind == "short"), (kind, ctx.last_schedule())
+            for p in range(200):
+                o = int(descs[p]["out_off"])
+                assert np.array_equal(got[o:o + n, 0], want[p]), (kind, p)
+    finally:
+        ctx.close()

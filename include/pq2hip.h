@@ -251,7 +251,7 @@ typedef struct pq2_dict_ref {
  * `value_size` is 4 (i32, f32), 8 (i64, f64) or 12 (int96); page i's values go to
  * d_out + descs[i].out_off * value_size (d_out 8-byte aligned).  Where the
  * lookup happens inside the decode kernel (batches that take ring_kernel, pages
- * of at most 12 bits, dictionaries of at most 48 KiB) the indices never exist in
+ * of at most 16 bits, dictionaries of at most 48 KiB) the indices never exist in
  * device memory; otherwise they pass through a buffer the context owns.  An
  * index that is not below
  * dict_len is Error::OutOfSpec in the reference

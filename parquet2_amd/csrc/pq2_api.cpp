@@ -62,6 +62,7 @@ hipError_t pq2_launch_ring_dict(const void *pages, uint32_t n_pages, int32_t *st
                                 uint32_t epoch, const uint32_t *tile_mask, const void *dicts, uint32_t value_words, uint32_t max_dict_bytes,
                                 const void *nulls, const uint32_t *go, hipStream_t stream);
 uint32_t pq2_ring_nullable_max_dict_bytes();
+uint32_t pq2_ring_nullable_max_bits();
 hipError_t pq2_launch_rowdir(const void *nulls, uint32_t n_pages, hipStream_t stream);  // pq2_optional.hip
 uint32_t pq2_rowdir_step();
 hipError_t pq2_launch_nullable_status(int32_t *status, const int32_t *level_status, uint32_t n_pages, hipStream_t stream);
@@ -1127,7 +1128,7 @@ int32_t pq2_decode_optional_dict_batch_device(pq2_ctx *ctx, const void *d_in, ui
             idx_max_bits = std::max(idx_max_bits, idx_descs[i].num_bits);  // (a width above 32 fails the page: not here)
             dict_max_bytes = std::max<uint64_t>(dict_max_bytes, uint64_t(dicts[i].dict_len) * value_size);
         }
-        if (rows_knob && idx_max_bits <= pq2_ring_dict_max_bits() && dict_max_bytes <= pq2_ring_nullable_max_dict_bytes()) {
+        if (rows_knob && idx_max_bits <= pq2_ring_nullable_max_bits() && dict_max_bytes <= pq2_ring_nullable_max_dict_bytes()) {
             const uint64_t step = pq2_rowdir_step();
             uint64_t dir_words = 0;
             std::vector<uint64_t> dir_at(n_pages);

@@ -1772,7 +1772,8 @@ constexpr uint32_t kRingFlagTurns = 2u;           // ... the workgroups of a com
 constexpr uint32_t kRingFlagStageShift = 8;       // ... from this bit on: where in LDS the expanding waves' StageSinks begin (kNullable)
 constexpr uint32_t kRingTurnsMaxBits = 20;        // the widest page of a batch that is given turns
 constexpr uint32_t kRingTurnsMinPages = 1025;     // ... and its fewest pages: one more than 256 compute units hold workgroups
-constexpr uint32_t kRingDictMaxBits = 12;  // widest index the kernels with a dictionary are built for
+constexpr uint32_t kRingDictMaxBits = 16;      // widest index the kernels with a dictionary are built for
+constexpr uint32_t kRingNullableMaxBits = 12;  // ... and those that write the rows of nullable pages
 
 // kWords = 0: the page's values are the decoded u32 (IndexSink).  kWords = 1, 2, 3: they are indices into the page's
 // dictionary of kWords-dword values, which the workgroup copies to LDS (from byte `dict_at` of its LDS on) before
@@ -2018,7 +2019,7 @@ __global__ __launch_bounds__(kRingThreads, PQ2_RING_MIN_WAVES) void ring_kernel(
                     uint16_t *const stage = (uint16_t *)mine;
                     uint32_t *const wbuf = (uint32_t *)(mine + kRowDirStep * 2u);
                     StageSink sink = {stage};
-                    static_assert(kRingDictMaxBits == 12, "the cases below");
+                    static_assert(kRingNullableMaxBits == 12, "the cases below");
                     switch (w) {
                         PQ2_W(1) PQ2_W(2) PQ2_W(3) PQ2_W(4) PQ2_W(5) PQ2_W(6) PQ2_W(7) PQ2_W(8)
                         PQ2_W(9) PQ2_W(10) PQ2_W(11) PQ2_W(12)
@@ -2038,10 +2039,10 @@ __global__ __launch_bounds__(kRingThreads, PQ2_RING_MIN_WAVES) void ring_kernel(
                     __builtin_amdgcn_wave_barrier();  // (the next span's indices go where these lay)
                 } else {
                     DictSink<kWords> sink = {(out_u32 *)value_addr + (size_t)span_first * kWords, dict_lds, dict_len, false};
-                    static_assert(kRingDictMaxBits == 12, "the cases below");
+                    static_assert(kRingDictMaxBits == 16, "the cases below");
                     switch (w) {
                         PQ2_W(1) PQ2_W(2) PQ2_W(3) PQ2_W(4) PQ2_W(5) PQ2_W(6) PQ2_W(7) PQ2_W(8)
-                        PQ2_W(9) PQ2_W(10) PQ2_W(11) PQ2_W(12)
+                        PQ2_W(9) PQ2_W(10) PQ2_W(11) PQ2_W(12) PQ2_W(13) PQ2_W(14) PQ2_W(15) PQ2_W(16)
                         case 0:  // every index is 0
                             ring_fill_span(sink, 0u, span_n, lane);
                             break;

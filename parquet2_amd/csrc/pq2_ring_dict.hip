@@ -7,6 +7,7 @@
 #include "pq2_ring.h"
 
 extern "C" uint32_t pq2_ring_dict_max_bits() { return pq2::kRingDictMaxBits; }
+extern "C" uint32_t pq2_ring_nullable_max_bits() { return pq2::kRingNullableMaxBits; }
 // the largest dictionary (bytes) a workgroup keeps in LDS beside its ring
 extern "C" uint32_t pq2_ring_dict_max_bytes() { return 49152u; }
 
@@ -41,7 +42,7 @@ extern "C" hipError_t pq2_launch_ring_dict(const void *pages, uint32_t n_pages, 
     const uint32_t dict_at = pq2::ring_lds_bytes(ring_bytes);
     static_assert(pq2::ring_lds_bytes(16384u) % 16u == 0u, "the dictionary begins at a 16-byte boundary");
     const uint32_t lds_bytes = dict_at + extra;
-    const uint32_t flags = (n_pages >= pq2::kRingTurnsMinPages ? pq2::kRingFlagTurns : 0u) |  // (indices of at most 12 bits)
+    const uint32_t flags = (n_pages >= pq2::kRingTurnsMinPages ? pq2::kRingFlagTurns : 0u) |  // (indices of at most 16 bits)
                            ((dict_at + dict_bytes) << pq2::kRingFlagStageShift);
 #define PQ2_LAUNCH_AS(WORDS, NULLABLE)                                                                                \
     if (lds_bytes > 65536u) { /* more than 64 KiB of dynamic LDS has to be asked for */                               \

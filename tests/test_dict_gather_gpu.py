@@ -79,7 +79,7 @@ def test_gather_matches_oracle(ctx, oracle, value_size):
 
 @pytest.mark.parametrize("value_size", [4, 8, 12])
 def test_lookup_inside_the_decode_kernel(ctx, oracle, value_size):
-    """Pages of at most 12 bits with dictionaries of at most 48 KiB: where ring_kernel decodes the batch, the lookup
+    """Pages of at most 16 bits with dictionaries of at most 48 KiB: where ring_kernel decodes the batch, the lookup
     happens inside it (no buffer of indices).  Every kind of span: long RLE runs, mixed runs, width 0, pages that end
     inside the stream and behind it, values at every alignment the value size allows, a dictionary that misses
     indices, a stream on which the reference panics."""
@@ -90,11 +90,12 @@ def test_lookup_inside_the_decode_kernel(ctx, oracle, value_size):
     dict_off = 0
     shapes = [(1, 200001, 400.0, 30.0), (2, 50000, 3.0, 5.0), (3, 4096, 20.0, 90.0), (7, 9000, 20.0, 90.0),
               (10, 65536, 64.0, 256.0), (12, 300000, 64.0, 256.0), (12, 123, 2.0, 9.0), (0, 777, 0, 0),
-              (9, 30000, 1000.0, 8.0), (11, 70000, 5.0, 600.0), (5, 1, 1.0, 1.0), (4, 40000, 1.5, 2.0)]
+              (9, 30000, 1000.0, 8.0), (11, 70000, 5.0, 600.0), (5, 1, 1.0, 1.0), (4, 40000, 1.5, 2.0),
+              (13, 50000, 30.0, 100.0), (14, 120000, 64.0, 256.0), (16, 33000, 8.0, 40.0)]
     for p, (w, n, rep, dist) in enumerate(shapes * 2):
         stream = synth.dict_page(synth.seed_for(2, 80 + p), n, w, rep, dist)[0] if w else np.zeros(0, dtype=np.uint8)
         want = n + 50 if p % 3 == 0 else n if p % 3 == 1 else max(1, n // 2)
-        if p == 13:  # an RLE run whose value byte is missing: the reference panics (decoder.rs:59-60)
+        if p == 16:  # an RLE run whose value byte is missing: the reference panics (decoder.rs:59-60)
             stream = np.array([0x10, 0x01], dtype=np.uint8)
             w, want = 12, 64
         batch.chunks.append(np.zeros(1 + p % 4, np.uint8))

@@ -49,7 +49,8 @@ hipError_t pq2_launch_bitunpack64(const void *d_packed, uint32_t packed_len, uin
 hipError_t pq2_launch_delta(const void *pages, uint32_t n_pages, void *results, hipStream_t stream);
 int32_t pq2_noalloc_setup(int32_t device, uint8_t **out);  // pq2_noalloc.hip
 hipError_t pq2_launch_ring(const void *pages, uint32_t n_pages, int32_t *status, uint32_t *cu_tickets, uint32_t epoch,
-                           uint32_t max_bits, const uint32_t *tile_mask, const uint32_t *go, hipStream_t stream);  // pq2_ring.hip
+                           uint32_t max_bits, const uint32_t *tile_mask, const uint32_t *go, hipEvent_t begin, hipEvent_t end,
+                           hipStream_t stream);  // pq2_ring.hip
 hipError_t pq2_launch_density(const void *pages, uint32_t n_pages, void *seen, float scout_us, float ring_fixed_us,
                               float per_header_us, float values_us, float turns, uint32_t *go, uint32_t *host_words,
                               uint32_t seq, hipStream_t stream);  // pq2_density.hip
@@ -587,18 +588,26 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
         PQ2_HIP(ctx, hipStreamWaitEvent(es[0], ctx->fork, 0));
         PQ2_HIP(ctx, hipStreamWaitEvent(es[1], ctx->fork, 0));
     }
-    auto stamped = [&](bool expand, hipStream_t on, auto &&launch) -> int32_t {
+    // `kernel_events`: the launch is one kernel whose launcher takes the two events itself (the kernel's own start and
+    // end: what rocprofv3 reports for it); else the events are recorded in the stream around whatever is launched.
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    auto stamped = [&](bool expand, hipStream_t on, auto &&launch, bool kernel_events = false) -> int32_t {
         pq2_ctx::Stamp stamp{nullptr, nullptr, expand};
+        ev_begin = ev_end = nullptr;
         if (ctx->profiling) {
             PQ2_HIP(ctx, hipEventCreate(&stamp.begin));
             PQ2_HIP(ctx, hipEventCreate(&stamp.end));
-            PQ2_HIP(ctx, hipEventRecord(stamp.begin, on));
+            if (kernel_events)
+                ev_begin = stamp.begin, ev_end = stamp.end;
+            else
+                PQ2_HIP(ctx, hipEventRecord(stamp.begin, on));
         }
         PQ2_HIP(ctx, launch());
         if (ctx->profiling) {
-            PQ2_HIP(ctx, hipEventRecord(stamp.end, on));
+            if (!kernel_events) PQ2_HIP(ctx, hipEventRecord(stamp.end, on));
             ctx->stamps.push_back(stamp);
         }
+        ev_begin = ev_end = nullptr;
         return PQ2_OK;
     };
     // The descriptors say ring_kernel -- but a page of short runs takes its one walking wave far longer than the
@@ -664,11 +673,11 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
                                                  ctx->ring_epoch++, bits->d_meta, stream);
                  if (ring)
                      return pq2_launch_ring(d_pages, static_cast<uint32_t>(n_pages), d_status, ring_tickets,
-                                            ctx->ring_epoch++, max_bits, d_tile_mask, d_go, stream);
+                                            ctx->ring_epoch++, max_bits, d_tile_mask, d_go, ev_begin, ev_end, stream);
                  return pq2_launch_decode(d_pages, static_cast<uint32_t>(n_pages), ctx->d_resume.ptr, d_run_pos, d_status,
                                           ctx->d_state.ptr, static_cast<uint32_t *>(ctx->d_tickets.ptr), max_bits,
                                           d_tile_mask, stream);
-             })))
+             }, ring && !fused && !bits)))
             return st;
         rounds = 0;
     }

@@ -20,7 +20,7 @@
 
 extern "C" hipError_t pq2_launch_ring(const void *pages, uint32_t n_pages, int32_t *status, uint32_t *cu_tickets,
                                       uint32_t epoch, uint32_t max_bits, const uint32_t *tile_mask, const uint32_t *go,
-                                      hipStream_t stream);
+                                      hipEvent_t begin, hipEvent_t end, hipStream_t stream);
 extern "C" uint32_t pq2_ring_ticket_bytes();
 
 namespace {
@@ -152,7 +152,7 @@ extern "C" int32_t pq2_decode_batch_device_noalloc(int32_t device_id, const void
                        (uint64_t) reinterpret_cast<uintptr_t>(d_out), out_values, max_bits, pages, desc_status);
     if (hipGetLastError() != hipSuccess) return PQ2_DEVICE_ERROR;
     if (pq2_launch_ring(pages, n, stream_status, reinterpret_cast<uint32_t *>(base + kOffTickets), 0u, max_bits, nullptr,
-                        nullptr, stream) != hipSuccess)
+                        nullptr, nullptr, nullptr, stream) != hipSuccess)
         return PQ2_DEVICE_ERROR;
     hipLaunchKernelGGL(noalloc_status_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, desc_status,
                        stream_status, n, d_status);

@@ -1,4 +1,6 @@
 // ring_kernel for plain u32 output: the launcher (the kernel itself: pq2_ring.h).
+#include <hip/hip_ext.h>
+
 #include "pq2_ring.h"
 
 #ifdef PQ2_RING_TIMING
@@ -26,9 +28,11 @@ extern "C" uint32_t pq2_ring_ticket_bytes() { return pq2::kRingCuTickets * 4u; }
 // width.  `max_bits`: the largest width of a page of the batch.
 // `epoch`: a count of the launches that use `cu_tickets` (see ring_pick_walker).
 // `go`: null, or a word of device memory that says, by the time the kernel runs, whether it is to run at all.
+// `begin`, `end`: null, or events that take the kernel's own start and end (pq2_ctx_enable_profiling: events recorded
+// around a launch also see the few microseconds between the launch's neighbours in the stream and the kernel).
 extern "C" hipError_t pq2_launch_ring(const void *pages, uint32_t n_pages, int32_t *status, uint32_t *cu_tickets,
                                       uint32_t epoch, uint32_t max_bits, const uint32_t *tile_mask, const uint32_t *go,
-                                      hipStream_t stream) {
+                                      hipEvent_t begin, hipEvent_t end, hipStream_t stream) {
     if (n_pages == 0) return hipSuccess;
     uint32_t ring_bytes = 32768u;
     if (const char *v = getenv("PQ2_RING_BYTES")) {  // tuning knob: 16384, 32768 or 65536
@@ -41,6 +45,18 @@ extern "C" hipError_t pq2_launch_ring(const void *pages, uint32_t n_pages, int32
                            (n_pages >= pq2::kRingTurnsMinPages && max_bits > pq2::kRingWholeTileBits && max_bits <= pq2::kRingTurnsMaxBits
                                 ? pq2::kRingFlagTurns
                                 : 0u);
+    // (the launch with events only where they are asked for: a plain launch can be captured into a graph)
+#define PQ2_RING_LAUNCH(WIDE)                                                                                              \
+    if (begin || end)                                                                                                      \
+        hipExtLaunchKernelGGL((pq2::ring_kernel<WIDE, 0>), dim3(n_pages), dim3(pq2::kRingThreads), lds_bytes, stream,      \
+                              begin, end, 0, (const pq2::PageDev *)pages, n_pages, status, cu_tickets, ring_bytes,         \
+                              tile_mask, (const pq2::RingDict *)nullptr, 0u, flags, epoch, (uint32_t *)nullptr, go,        \
+                              (const pq2::RingNullable *)nullptr);                                                         \
+    else                                                                                                                   \
+        hipLaunchKernelGGL((pq2::ring_kernel<WIDE, 0>), dim3(n_pages), dim3(pq2::kRingThreads), lds_bytes, stream,         \
+                           (const pq2::PageDev *)pages, n_pages, status, cu_tickets, ring_bytes, tile_mask,                \
+                           (const pq2::RingDict *)nullptr, 0u, flags, epoch, (uint32_t *)nullptr, go,                      \
+                           (const pq2::RingNullable *)nullptr)
     if (max_bits > pq2::kRingNarrowBits) {  // ring_kernel<true, .>: every width, and a header walk that keeps four more bytes per run
         // more than 64 KiB of dynamic LDS has to be asked for (per device; the call is cheap)
         if (lds_bytes > 65536u) {
@@ -48,14 +64,11 @@ extern "C" hipError_t pq2_launch_ring(const void *pages, uint32_t n_pages, int32
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL((pq2::ring_kernel<true, 0>), dim3(n_pages), dim3(pq2::kRingThreads), lds_bytes, stream,
-                           (const pq2::PageDev *)pages, n_pages, status, cu_tickets, ring_bytes, tile_mask,
-                           (const pq2::RingDict *)nullptr, 0u, flags, epoch, (uint32_t *)nullptr, go, (const pq2::RingNullable *)nullptr);
+        PQ2_RING_LAUNCH(true);
     } else {
-        hipLaunchKernelGGL((pq2::ring_kernel<false, 0>), dim3(n_pages), dim3(pq2::kRingThreads), lds_bytes, stream,
-                           (const pq2::PageDev *)pages, n_pages, status, cu_tickets, ring_bytes, tile_mask,
-                           (const pq2::RingDict *)nullptr, 0u, flags, epoch, (uint32_t *)nullptr, go, (const pq2::RingNullable *)nullptr);
+        PQ2_RING_LAUNCH(false);
     }
+#undef PQ2_RING_LAUNCH
     return hipGetLastError();
 }
 

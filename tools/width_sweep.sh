@@ -2,7 +2,7 @@
 # ring_kernel over config-2 pages of 2^20 values at other bit widths: one line per width.
 R=$GRAFT_REPO_ROOT
 for w in ${WIDTHS:-1 2 3 4 5 6 8 10 12 14 16 17 20 24 28 32}; do
-  pages=2048; [ $w -gt 24 ] && pages=1024
+  pages=${PAGES:-2048}
   PQ2_MODE=ring timeout -k 10 200 python3 $R/bench.py --no-cpu-baseline --no-other-configs --pages $pages --bits $w --steps 10 --warmup 2 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read()); r=d['roofline']

@@ -216,6 +216,7 @@ struct pq2_ctx {
     hipEvent_t density_done = nullptr;
     uint32_t density_seq = 0;
     bool probe_density = true;  // PQ2_DENSITY_PROBE=0: the descriptors alone decide (A/B runs)
+    bool optional_bits = true, optional_fused = true;  // PQ2_OPTIONAL_BITS=0, PQ2_OPTIONAL_FUSED=0 (A/B runs, tests)
     uint32_t last_density_headers = 0;  // largest estimated header count of a page, if the last batch was probed
     void *h_gather = nullptr;
     size_t h_gather_cap = 0;
@@ -784,6 +785,8 @@ int32_t pq2_ctx_create(int32_t device_id, pq2_ctx **out) {
     if (const char *v = std::getenv("PQ2_EXPAND_STREAMS")) ctx->one_expand_stream = std::atoi(v) != 2;
     if (const char *v = std::getenv("PQ2_MODE")) (void)pq2_ctx_set_schedule(ctx, v);  // another word: as without
     if (const char *v = std::getenv("PQ2_DENSITY_PROBE")) ctx->probe_density = std::atoi(v) != 0;
+    if (const char *v = std::getenv("PQ2_OPTIONAL_BITS")) ctx->optional_bits = std::atoi(v) != 0;
+    if (const char *v = std::getenv("PQ2_OPTIONAL_FUSED")) ctx->optional_fused = std::atoi(v) != 0;
     if (const char *v = std::getenv("PQ2_ROUND_SPLIT")) {
         double a = 0, b = 0, c = 0;
         if (std::sscanf(v, "%lf,%lf,%lf", &a, &b, &c) == 3 && 0 <= a && a <= b && b <= c && c <= 1)
@@ -1083,11 +1086,8 @@ int32_t pq2_decode_optional_dict_batch_device(pq2_ctx *ctx, const void *d_in, ui
     // bitmap mode, which is bound by the header walks and moves next to nothing) on a stream of its own while this
     // context decodes the index streams, and the scatter reads one bit per row instead of a u32 that had to be written
     // first.  Same values, validity and statuses as the path below (a level is valid where it equals 1 either way).
-    static const bool bits_knob = [] {  // PQ2_OPTIONAL_BITS=0: levels as u32 (A/B runs)
-        const char *v = std::getenv("PQ2_OPTIONAL_BITS");
-        return !v || std::atoi(v) != 0;
-    }();
-    bool by_bits = bits_knob && n_pages >= kOptionalWholePages &&
+    // (PQ2_OPTIONAL_BITS=0 when the context was created: levels as u32, for A/B runs)
+    bool by_bits = ctx->optional_bits && n_pages >= kOptionalWholePages &&
                    (ctx->mode == pq2_ctx::kAuto || ctx->mode == pq2_ctx::kRing);
     for (uint64_t i = 0; by_bits && i < n_pages; ++i)
         by_bits = max_def_levels[i] == 1 && def_descs[i].num_bits == 1 && def_descs[i].num_values <= PQ2_MAX_PAGE_VALUES &&
@@ -1126,18 +1126,14 @@ int32_t pq2_decode_optional_dict_batch_device(pq2_ctx *ctx, const void *d_in, ui
         // spans of 2048 valid rows begin: rowdir_kernel), then ring_kernel over the index streams, whose expanding waves
         // keep a span's indices in LDS and write the span's ROWS -- values, nulls and validity bytes.  What moves
         // through device memory is the streams, the bitmaps (a bit per row, written and read) and the result.
-        // (PQ2_OPTIONAL_FUSED=0: the indices go through memory, optional_bits_kernel places them.)
-        static const bool rows_knob = [] {
-            const char *v = std::getenv("PQ2_OPTIONAL_FUSED");
-            return !v || std::atoi(v) != 0;
-        }();
+        // (PQ2_OPTIONAL_FUSED=0 when the context was created: the indices go through memory, optional_bits_kernel places them.)
         uint32_t idx_max_bits = 0;
         uint64_t dict_max_bytes = 0;
         for (uint64_t i = 0; i < n_pages; ++i) {
             idx_max_bits = std::max(idx_max_bits, idx_descs[i].num_bits);  // (a width above 32 fails the page: not here)
             dict_max_bytes = std::max<uint64_t>(dict_max_bytes, uint64_t(dicts[i].dict_len) * value_size);
         }
-        if (rows_knob && idx_max_bits <= pq2_ring_nullable_max_bits() && dict_max_bytes <= pq2_ring_nullable_max_dict_bytes()) {
+        if (ctx->optional_fused && idx_max_bits <= pq2_ring_nullable_max_bits() && dict_max_bytes <= pq2_ring_nullable_max_dict_bytes()) {
             const uint64_t step = pq2_rowdir_step();
             uint64_t dir_words = 0;
             std::vector<uint64_t> dir_at(n_pages);

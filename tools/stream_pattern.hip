@@ -91,7 +91,7 @@ static double run(const uint8_t *in, uint8_t *out, uint32_t regions, uint32_t gr
     return ms / reps;
 }
 
-// ---- what round 1's tools/ubench/membw.hip measured (5.5-5.7 TB/s for 1 read : 4 written), in this file's terms ------
+// ---- what tools/ubench/membw.hip measures (5.5-5.7 TB/s for 1 read : 4 written), in this file's terms ------
 // pattern 3: no workgroup stays: a grid of total_steps / per workgroups, each doing `per` consecutive steps of kStep
 //            bytes written (and 3/8 of that read) and ending -- the hardware hands the pieces out in order, so all that
 //            is written at one time lies in one window that moves through memory once.

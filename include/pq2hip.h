@@ -283,7 +283,12 @@ int32_t pq2_decode_dict_batch_device(pq2_ctx *ctx, const void *d_in, uint64_t in
  * (DefLevelsDecoder::Bitmap), which yields the same rows except that a level
  * stream that ends early yields fewer rows there and null rows here.
  * status[i]: the level stream's status if not OK, else the index stream's,
- * else PQ2_OUT_OF_SPEC for a consumed index beyond the dictionary. */
+ * else PQ2_OUT_OF_SPEC for a consumed index beyond the dictionary.
+ * Batches of 256 pages and more whose pages all have max_def_level 1 do not
+ * expand their levels (validity bitmaps, as pq2_decode_validity_bitmap_batch_device
+ * makes them), and with indices of at most 12 bits and dictionaries of at most
+ * 16 KiB the decode kernel writes the rows itself: neither levels nor indices
+ * pass through device memory. */
 int32_t pq2_decode_optional_dict_batch_device(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes,
                                               const pq2_page_desc *def_descs, const pq2_page_desc *idx_descs,
                                               const uint32_t *max_def_levels, uint64_t n_pages, const void *d_dict,

@@ -2010,8 +2010,11 @@ __global__ __launch_bounds__(kRingThreads, PQ2_RING_MIN_WAVES) void ring_kernel(
                         dir_rows[0] = dir[0], dir_rows[1] = dir[1], dir_rows[2] = dir[2];
                     }
                     const bool last = span_first + span_n >= n;  // the rows behind the last index are the last span's too
-                    const uint32_t row_lo = __builtin_amdgcn_readfirstlane(i == 0 ? dir_rows[0] : dir_rows[1]);
-                    const uint32_t row_hi = last ? nl.rows : __builtin_amdgcn_readfirstlane(i == 0 ? dir_rows[1] : dir_rows[2]);
+                    // (clamped to the page: the bitmap of a page whose level stream failed holds whatever the memory held,
+                    // and so does its directory -- such a page's rows are not defined, its neighbours' are)
+                    const uint32_t page_rows = __builtin_amdgcn_readfirstlane(nl.rows);
+                    const uint32_t row_hi = last ? page_rows : min(page_rows, __builtin_amdgcn_readfirstlane(i == 0 ? dir_rows[1] : dir_rows[2]));
+                    const uint32_t row_lo = min(row_hi, __builtin_amdgcn_readfirstlane(i == 0 ? dir_rows[0] : dir_rows[1]));
                     const __amdgpu_buffer_rsrc_t bits = make_rsrc(nl.bitmap_addr, ((nl.rows + 31u) >> 5) * 4u);
                     uint32_t x0 = __builtin_amdgcn_raw_buffer_load_b32(bits, ((row_lo >> 5) + lane) * 4u, 0, 0);
                     uint32_t x1 = __builtin_amdgcn_raw_buffer_load_b32(bits, ((row_lo >> 5) + 64u + lane) * 4u, 0, 0);

@@ -25,6 +25,11 @@ With no --workload the line is the default workload's, and it carries the other 
 size SURVEY quotes config 2 on; the 75 / 25 page mix of configs[4]; bit-unpack at every width), each with its step
 time, rate, dominant kernel and roofline fraction.  --no-other-configs leaves them out (A/B runs, counter passes).
 
+The K timed steps run with nothing but the decoder's own work in the stream: `value` and `ms_per_step` are theirs.
+The duration of the dominant kernel (`roofline`) is taken with HIP events over a second run of the same K steps
+directly behind them -- every event holds the stream up for some 5 microseconds, 15 a step, which is a tenth of a
+batch of few pages; the line says what a step took with the events in.
+
 Before anything is timed, every distinct page of a batch is decoded by the CPU oracle (oracle/: the plain-C
 restatement of the reference decoder) and the GPU's output of every page of the batch has to be identical to it.
 
@@ -479,7 +484,10 @@ def run_pages(a, env):
 
     for _ in range(a.warmup):
         step()
-    ctx.enable_profiling(True)
+    # The timed region: K steps, nothing else in the stream.  The kernels' own durations are taken with HIP events over
+    # a second run of the same K steps right behind it: events, whether recorded in the stream or handed to a kernel's
+    # launch, hold the stream up for some 5 microseconds each -- 15 a step, a tenth of a batch of few pages -- and
+    # `value` is the rate of the work, not of the work and its measurement.
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
@@ -492,6 +500,12 @@ def run_pages(a, env):
         dist.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    ctx.enable_profiling(True)
+    t1 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed_with_events = time.perf_counter() - t1
     parse_ms, expand_ms, batches, expand_launches = ctx.kernel_times()
     ctx.enable_profiling(False)
     schedule = ctx.last_schedule()
@@ -548,6 +562,8 @@ def run_pages(a, env):
             "traffic_source": traffic_source,
             "algorithmic_bytes_per_launch": int(bytes_per_launch),
             "avg_launch_ms": round(expand_avg_ms, 4), "launches_per_step": rounds,
+            "kernel_times_from": "HIP events over a second run of the same %d steps right behind the timed ones "
+                                 "(%.4f ms per step with the events in the stream)" % (a.steps, 1e3 * elapsed_with_events / a.steps),
             "parse_kernel_ms_per_step": round(parse_ms / max(batches, 1), 4),
             "%s_ms_per_step" % schedule.split("+")[-1]: round(expand_ms / max(batches, 1), 4),
         },

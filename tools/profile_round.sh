@@ -58,7 +58,7 @@ for fused in 1 0; do
 done
 timeout -k 10 200 python3 $R/tools/scout_rounds.py > $O/scout_rounds.txt 2>&1 || exit 1
 timeout -k 10 200 python3 $R/tools/bench_bitunpack64.py > $O/bitunpack64.json 2> $O/bitunpack64.err || exit 1
-(timeout -k 10 200 python3 $R/tools/bench_optional.py 4096 262144 4 && PQ2_OPTIONAL_BITS=0 timeout -k 10 200 python3 $R/tools/bench_optional.py 4096 262144 4 && timeout -k 10 200 python3 $R/tools/bench_optional.py 4096 262144 8 && timeout -k 10 200 python3 $R/tools/bench_optional.py 16 4194304 4 && PQ2_OPTIONAL_SEG_ROWS=0 timeout -k 10 200 python3 $R/tools/bench_optional.py 16 4194304 4) > $O/optional.txt 2> $O/optional.err || exit 1
+(timeout -k 10 200 python3 $R/tools/bench_optional.py 4096 262144 4 30 && PQ2_OPTIONAL_FUSED=0 timeout -k 10 200 python3 $R/tools/bench_optional.py 4096 262144 4 30 && PQ2_OPTIONAL_BITS=0 timeout -k 10 200 python3 $R/tools/bench_optional.py 4096 262144 4 30 && timeout -k 10 200 python3 $R/tools/bench_optional.py 4096 262144 8 30 && timeout -k 10 200 python3 $R/tools/bench_optional.py 16 4194304 4 && PQ2_OPTIONAL_SEG_ROWS=0 timeout -k 10 200 python3 $R/tools/bench_optional.py 16 4194304 4) > $O/optional.txt 2> $O/optional.err || exit 1
 timeout -k 10 300 python3 $R/tools/schedule_choice.py > $O/schedule_choice.txt 2> $O/schedule_choice.err || exit 1
 cd $R
 for f in $O/bench_*.json $O/host_path.json; do echo "== $f"; cut -c1-300 $f; done

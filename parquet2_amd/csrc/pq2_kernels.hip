@@ -1793,6 +1793,12 @@ __device__ int32_t delta_blocks(DeltaStream &s, uint32_t lane, uint32_t *tbl_sta
 // absurd -- and for every other shape of stream, wave 0 goes on alone with delta_blocks from that block on, which
 // also decides the stream's status: the chunked path accepts only what delta_blocks accepts.
 //
+// Blocks of 128 values in 1, 2 or 4 mini-blocks (`brief_shape`) have a shorter walk (the varint and the width bytes
+// lie in 12 bytes from a block's start: every lane does the same arithmetic on them, one readfirstlane per block)
+// and a shorter list (one 16-byte entry a block), and their expansion gives a lane two neighbouring values, stored
+// with one instruction through a buffer descriptor over the output; blocks whose widths are all at most
+// kDeltaNarrowBits take their running sums in 32 bits.  The same protocol, the same fallback.
+//
 // The waves of a workgroup are resident together, so every wait below ends: the walker waits for expanders that
 // have all they need, the expanders for a walker that always advances or says that it has stopped; the waits are
 // bounded all the same (status PQ2_DEVICE_ERROR).
@@ -1810,18 +1816,35 @@ constexpr uint32_t kDeltaBlockMost = kDeltaChunk / 16u;
 static_assert(10u + kDeltaMinis + kDeltaBlockMost * 8u + 15u <= kDeltaChunk && kDeltaListed <= 64u, "delta chunk");
 constexpr uint32_t kDeltaExpanders = 3;
 
-struct DeltaLists {  // what the walker says about one chunk
+struct alignas(16) DeltaLists {  // what the walker says about one chunk
     uint64_t blk_min[kDeltaListed];                      // min_delta
     uint64_t blk_sum[kDeltaListed];                      // (by the expanders) the sum of the block's deltas
     uint32_t blk_len[kDeltaListed];                      // values
     uint32_t blk_first[kDeltaListed];                    // index of the first one among the stream's deltas
-    uint16_t mini_start[kDeltaListed * kDeltaMinis];     // byte offset in the chunk
+    union {
+        uint16_t mini_start[kDeltaListed * kDeltaMinis];  // byte offset in the chunk
+        // blocks of 128 values in at most 4 mini-blocks, one entry a block: the eight stream bytes from the
+        // block's start on (x, y: min_delta's varint and what follows it), the four widths (z), the byte offset
+        // of the first mini-block in the chunk and, from bit 16 on, the bytes of the varint (w)
+        u32x4 brief[kDeltaListed];
+    };
     uint8_t mini_bits[kDeltaListed * kDeltaMinis];
     uint32_t listed;  // blocks; 0: the walker has stopped here and takes the rest by itself
     uint32_t last;    // the stream ends with this chunk
+    uint32_t first;   // blocks of 128: index of the first listed block's first value among the stream's deltas
+    uint32_t left;    // ... and the deltas of the stream from there on
 };
+constexpr uint32_t kDeltaNarrowBits = 24;  // 128 deltas of at most that many bits: their sum fits 32 bits
+// uleb128::decode over four bytes of a varint (the low seven bits of each, the first byte lowest)
+__device__ __forceinline__ uint32_t varint_half(uint32_t b) {
+    return (b & 0x7fu) | ((b >> 1) & 0x3f80u) | ((b >> 2) & 0x1fc000u) | ((b >> 3) & 0xfe00000u);
+}
 
-__global__ __launch_bounds__(256) void delta_kernel(const DeltaPage *__restrict__ pages, uint32_t n_pages,
+// (six workgroups on a compute unit: 80 registers a lane, a handful of rarely used values kept in scratch)
+#ifndef PQ2_DELTA_WAVES
+#define PQ2_DELTA_WAVES 6
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PQ2_DELTA_WAVES, PQ2_DELTA_WAVES))) void delta_kernel(const DeltaPage *__restrict__ pages, uint32_t n_pages,
                                                     DeltaResult *__restrict__ results) {
     __shared__ __attribute__((aligned(16))) uint8_t chunks[2][kDeltaChunk + 32];
     __shared__ DeltaLists lists[2];
@@ -1839,8 +1862,8 @@ __global__ __launch_bounds__(256) void delta_kernel(const DeltaPage *__restrict_
     uint64_t num_values = 0ull;
     // every wave reads the header for itself: all four hold the same stream state without an exchange
     int32_t status = delta_open(pages[page], lane, wave == 0u, s, num_values);
-    auto report = [&](int32_t st) {
-        if (threadIdx.x == 0u) {
+    auto report = [&](int32_t st) {  // (by the walker, or by every wave alike)
+        if (wave == 0u && lane == 0u) {
             DeltaResult r;
             r.status = st;
             r.consumed = st == 0 ? s.pos - s.delta : 0u;
@@ -1855,6 +1878,11 @@ __global__ __launch_bounds__(256) void delta_kernel(const DeltaPage *__restrict_
     const uint32_t per_mini32 = s.per_mini32;
     const bool chunked = s.block_size_small != 0u && s.block_size_small <= kDeltaBlockMost &&
                          s.num_mini_blocks <= kDeltaMinis && per_mini32 != 0u;
+    // blocks of 128 values in 1, 2 or 4 mini-blocks (what the writers at large produce): a shorter walk, shorter lists
+    // (and values whose byte offsets in the output fit 32 bits: they are stored through a buffer descriptor)
+    const bool brief_shape = s.block_most == 128ull && s.num_mini_blocks <= 4ull && num_values <= 0x10000000ull;
+    // bytes of a mini-block = its width << per8_shift (a mini-block holds a multiple of 8 values, here 32, 64 or 128)
+    const uint32_t per8_shift = brief_shape ? (uint32_t)__builtin_ctz(per_mini32) - 3u : 0u;
     if (chunked) {
         if (threadIdx.x < 4u) *(u32x4 *)(chunks[threadIdx.x >> 1] + kDeltaChunk + (threadIdx.x & 1u) * 16u) = u32x4{0u, 0u, 0u, 0u};
         if (threadIdx.x == 0u) walked = 0u, summed = 0u, expanded[0] = 0u, expanded[1] = 0u, expanded[2] = 0u;
@@ -1870,6 +1898,9 @@ __global__ __launch_bounds__(256) void delta_kernel(const DeltaPage *__restrict_
         };
         if (wave == 0u) {
             // ---- the walker ----
+            // The walk is one chain of dependent steps, a few dozen instructions per block, and sets the pace of
+            // the workgroup: its instructions go before those of the waves it shares the SIMD with.
+            __builtin_amdgcn_s_setprio(3);
             const uint32_t block_most = (uint32_t)s.block_most;
             const uint32_t minis = (uint32_t)s.num_mini_blocks;
             for (uint32_t c = 0;; ++c) {
@@ -1893,6 +1924,57 @@ __global__ __launch_bounds__(256) void delta_kernel(const DeltaPage *__restrict_
                 // Block::try_new and advance_miniblock as in delta_blocks, out of the chunk; anything but a
                 // well-formed block that lies in the chunk whole ends the list
                 uint32_t listed = 0u;
+                if (brief_shape) {
+                    // The same checks, every lane alike and without branches but one: the varint (up to 8 bytes; a
+                    // longer one ends the list) and the four width bytes lie in 12 bytes from the block's start,
+                    // read as four dwords.  A block whose first 12 bytes are not all in the stream ends the list
+                    // as well.  Only the stream's last block may open fewer than all of its mini-blocks.
+                    if (lane == 0u) ls.first = s.done, ls.left = s.remaining;
+                    // (the stream's state is the same in every lane: into scalar registers, and the loop's
+                    // conditions with it)
+                    const uint32_t end = __builtin_amdgcn_readfirstlane(s.end);
+                    const uint32_t remaining = __builtin_amdgcn_readfirstlane(s.remaining);
+                    const uint32_t mini_shift = per8_shift + 3u;
+                    const uint32_t blocks_left = (remaining + 127u) >> 7;
+                    const uint32_t want = blocks_left < kDeltaListed ? blocks_left : kDeltaListed;
+                    const uint32_t tail = remaining - (blocks_left - 1u) * 128u;  // values of the last block
+                    const uint32_t tail_minis = ((tail - 1u) >> mini_shift) + 1u;
+                    const uint32_t tail_mask = tail_minis < 4u ? (1u << (8u * tail_minis)) - 1u : ~0u;
+                    const uint32_t whole_mask = minis < 4u ? (1u << (8u * minis)) - 1u : ~0u;
+                    const uint32_t chunk_lo = __builtin_amdgcn_readfirstlane(chunk_a);
+                    const uint32_t limit = end < chunk_lo + kDeltaChunk ? end : chunk_lo + kDeltaChunk;  // a listed block ends at or before it
+                    uint32_t pos = __builtin_amdgcn_readfirstlane(s.pos);
+                    for (; listed < want; ++listed) {
+                        if (pos + 12u > end) break;
+                        const uint32_t a = pos - chunk_lo;
+                        const uint32_t *p = (const uint32_t *)(chunk + (a & ~3u));
+                        const uint32_t x0 = p[0], x1 = p[1], x2 = p[2], x3 = p[3];
+                        const uint32_t sh = a * 8u;  // (the funnel shift takes the low five bits)
+                        const uint32_t b0 = __builtin_amdgcn_alignbit(x1, x0, sh);
+                        const uint32_t b1 = __builtin_amdgcn_alignbit(x2, x1, sh);
+                        const uint32_t b2 = __builtin_amdgcn_alignbit(x3, x2, sh);
+                        // the varint's last byte is the first one without bit 7; `behind`: 8 * the varint's bytes
+                        const uint32_t e0 = ~b0 & 0x80808080u, e1 = ~b1 & 0x80808080u;
+                        const uint32_t behind = (uint32_t)__builtin_ctzll(((uint64_t)e1 << 32) | e0) + 1u;
+                        // the four bytes behind the varint
+                        const uint32_t lo = behind < 32u ? b0 : behind < 64u ? b1 : b2;
+                        const uint32_t hi = behind < 32u ? b1 : b2;
+                        uint32_t widths = __builtin_amdgcn_alignbit(hi, lo, behind);
+                        widths &= listed + 1u == blocks_left ? tail_mask : whole_mask;
+                        const uint32_t over = (((widths & 0x7f7f7f7fu) + 0x3f3f3f3fu) | widths) & 0x80808080u;  // a width above 64
+                        const uint32_t total = __builtin_amdgcn_sad_u8(widths, 0u, 0u) << per8_shift;
+                        const uint32_t at = pos + minis + (behind >> 3);
+                        const uint32_t next = (e0 | e1) == 0u || over != 0u ? ~0u : at + total;
+                        const uint32_t next_pos = __builtin_amdgcn_readfirstlane(next);
+                        if (next_pos > limit) break;
+                        if (lane == 0u) ls.brief[listed] = u32x4{b0, b1, widths, (at - chunk_lo) | (behind << 13)};
+                        pos = next_pos;
+                    }
+                    const uint32_t taken = listed == blocks_left ? remaining : listed * 128u;
+                    s.pos = pos;
+                    s.done += taken;
+                    s.remaining -= taken;
+                } else
                 while (s.remaining != 0u && listed < kDeltaListed) {
                     if (!(s.pos + 64u <= chunk_hi || s.end <= chunk_hi)) break;
                     const uint32_t a = s.pos + lane;
@@ -1953,6 +2035,8 @@ __global__ __launch_bounds__(256) void delta_kernel(const DeltaPage *__restrict_
             const uint32_t mini_shift = (uint32_t)__builtin_ctz(per_mini32);
             uint64_t acc = s.acc;  // the last value before the chunk
             const bool small_blocks = s.block_most <= 128ull;
+            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+            const __amdgpu_buffer_rsrc_t out_rsrc = make_rsrc((uint64_t)s.out, brief_shape ? (uint32_t)num_values * 8u : 0u);
             for (uint32_t c = 0;; ++c) {
                 const uint8_t *const chunk = chunks[c & 1u];
                 DeltaLists &ls = lists[c & 1u];
@@ -1976,7 +2060,76 @@ __global__ __launch_bounds__(256) void delta_kernel(const DeltaPage *__restrict_
                 // block stay in registers until the block's first value is known.
                 constexpr uint32_t kKept = (kDeltaListed + kDeltaExpanders - 1u) / kDeltaExpanders;  // blocks per wave
                 uint64_t kept[kKept][2];
-                if (small_blocks) {
+                const uint32_t first0 = brief_shape ? __builtin_amdgcn_readfirstlane(ls.first) : 0u;
+                const uint32_t left0 = brief_shape ? __builtin_amdgcn_readfirstlane(ls.left) : 0u;
+                if (brief_shape) {
+                    // A lane takes the values 2 lane and 2 lane + 1 of a block (they lie in one mini-block, one
+                    // behind the other; the lane stores them with one instruction): 8 * their mini-block's
+                    // number, and the first one's number inside it.  kept[.][0] and [1]: the sums up to each.
+                    const uint32_t mini_shift = per8_shift + 3u;
+                    const uint32_t sh8 = ((2u * lane) >> mini_shift) * 8u;
+                    const uint32_t idx = (2u * lane) & (per_mini32 - 1u);
+#pragma unroll
+                    for (uint32_t i = 0; i < kKept; ++i) {
+                        const uint32_t k = e + i * kDeltaExpanders;
+                        kept[i][0] = kept[i][1] = 0ull;
+                        if (k < listed) {
+                            const u32x4 entry = ls.brief[k];
+                            const uint32_t widths = __builtin_amdgcn_readfirstlane(entry.z);
+                            const uint32_t at = __builtin_amdgcn_readfirstlane(entry.w) & 0xffffu;
+                            const uint32_t used = __builtin_amdgcn_readfirstlane(entry.w) >> 16;
+                            uint64_t min_delta;  // zigzag_leb128::decode of the varint's `used` bytes
+                            if (used <= 4u) {
+                                const uint32_t u = varint_half(__builtin_amdgcn_readfirstlane(entry.x) & (~0u >> (32u - 8u * used)));
+                                min_delta = (uint64_t)(int64_t)(int32_t)((u >> 1) ^ (0u - (u & 1u)));
+                            } else {
+                                const uint64_t bytes = (((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(entry.y) << 32) |
+                                                        (uint32_t)__builtin_amdgcn_readfirstlane(entry.x)) & (~0ull >> (64u - 8u * used));
+                                min_delta = zigzag((uint64_t)varint_half((uint32_t)bytes) |
+                                                   ((uint64_t)varint_half((uint32_t)(bytes >> 32)) << 28));
+                            }
+                            const uint32_t len = left0 - k * 128u < 128u ? left0 - k * 128u : 128u;
+                            // the packed value 2 lane: its width and its first bit in the chunk
+                            const uint32_t w = (widths >> sh8) & 0xffu;
+                            const uint32_t minis_before = __builtin_amdgcn_sad_u8(widths & ~(~0u << sh8), 0u, 0u);
+                            const uint32_t bit = ((at + (minis_before << per8_shift)) << 3) + idx * w;
+                            const bool narrow = (((widths & 0x7f7f7f7fu) + (0x80u - 1u - kDeltaNarrowBits) * 0x01010101u) & 0x80808080u) == 0u;
+                            if (narrow) {
+                                // 128 deltas of at most 24 bits: the sums of the packed values fit 32 bits, and
+                                // min_delta comes in by a multiplication.  Both values lie in three dwords.
+                                const uint32_t *src = (const uint32_t *)(chunk + ((bit >> 5) << 2));
+                                const uint32_t x0 = src[0], x1 = src[1], x2 = src[2];
+                                const uint32_t mask = (1u << w) - 1u;
+                                const uint32_t behind = (bit & 31u) + w;
+                                uint32_t field0 = __builtin_amdgcn_alignbit(x1, x0, bit) & mask;
+                                uint32_t field1 = __builtin_amdgcn_alignbit(behind < 32u ? x1 : x2, behind < 32u ? x0 : x1, behind) & mask;
+                                uint32_t n0 = 2u * lane + 1u, n1 = 2u * lane + 2u;  // terms up to each value
+                                if (len < 128u) {
+                                    field0 = n0 <= len ? field0 : 0u, field1 = n1 <= len ? field1 : 0u;
+                                    n0 = n0 < len ? n0 : len, n1 = n1 < len ? n1 : len;
+                                }
+                                const uint32_t upto = wave_inclusive_sum(field0 + field1);
+                                kept[i][0] = (uint64_t)n0 * min_delta + (upto - field1);
+                                kept[i][1] = (uint64_t)n1 * min_delta + upto;
+                            } else {
+                                uint64_t term[2];
+#pragma unroll
+                                for (uint32_t h = 0; h < 2u; ++h) {
+                                    const uint32_t from = bit + h * w;
+                                    const uint32_t *src = (const uint32_t *)(chunk + ((from >> 5) << 2));
+                                    const uint32_t x0 = src[0], x1 = src[1], x2 = w > 32u ? src[2] : 0u;
+                                    const uint64_t x = ((uint64_t)__builtin_amdgcn_alignbit(x2, x1, from) << 32) |
+                                                       __builtin_amdgcn_alignbit(x1, x0, from);
+                                    const uint64_t mask = w == 0u ? 0ull : (~0ull >> (64u - w));
+                                    term[h] = 2u * lane + h < len ? min_delta + (x & mask) : 0ull;
+                                }
+                                kept[i][1] = wave_inclusive_sum64(term[0] + term[1]);
+                                kept[i][0] = kept[i][1] - term[1];
+                            }
+                            if (lane == 63u) ls.blk_sum[k] = kept[i][1];
+                        }
+                    }
+                } else if (small_blocks) {
 #pragma unroll
                     for (uint32_t i = 0; i < kKept; ++i) {
                         const uint32_t k = e + i * kDeltaExpanders;
@@ -2009,7 +2162,26 @@ __global__ __launch_bounds__(256) void delta_kernel(const DeltaPage *__restrict_
                 const uint64_t upto = wave_inclusive_sum64(own);
                 const uint64_t before_block = acc + upto - own;
                 acc += lane_value64(upto, 63u);
-                if (small_blocks) {
+                if (brief_shape) {
+#pragma unroll
+                    for (uint32_t i = 0; i < kKept; ++i) {
+                        const uint32_t k = e + i * kDeltaExpanders;
+                        if (k < listed) {
+                            const uint64_t before = lane_value64(before_block, k);
+                            const uint64_t v0 = before + kept[i][0], v1 = before + kept[i][1];
+                            const uint32_t at = (1u + first0 + k * 128u + 2u * lane) * 8u;
+                            if (left0 - k * 128u >= 128u) {
+                                __builtin_amdgcn_raw_buffer_store_b128(u32x4{(uint32_t)v0, (uint32_t)(v0 >> 32), (uint32_t)v1, (uint32_t)(v1 >> 32)},
+                                                                       out_rsrc, at, 0, 0);
+                            } else {
+                                // the stream's last block: value by value through the descriptor, which drops
+                                // a store behind the stream's last value
+                                __builtin_amdgcn_raw_buffer_store_b64(u32x2{(uint32_t)v0, (uint32_t)(v0 >> 32)}, out_rsrc, at, 0, 0);
+                                __builtin_amdgcn_raw_buffer_store_b64(u32x2{(uint32_t)v1, (uint32_t)(v1 >> 32)}, out_rsrc, at + 8u, 0, 0);
+                            }
+                        }
+                    }
+                } else if (small_blocks) {
 #pragma unroll
                     for (uint32_t i = 0; i < kKept; ++i) {
                         const uint32_t k = e + i * kDeltaExpanders;

@@ -179,6 +179,65 @@ def test_generated_streams(ctx, oracle, block_size, num_mini_blocks):
     assert seen == {0: len(streams)}
 
 
+def values_of_deltas(first, deltas):
+    """The i64 values whose differences are `deltas` (wrapping, as the decoder's additions do)."""
+    out, v = [first], first
+    for d in deltas:
+        v = (v + d) & M64
+        out.append(v - (1 << 64) if v >> 63 else v)
+    return out
+
+
+@pytest.mark.parametrize("num_mini_blocks", [1, 2, 4])
+def test_blocks_of_128_values(ctx, oracle, num_mini_blocks):
+    """Blocks of 128 values in 1, 2 or 4 mini-blocks have a walk and an expansion of their own in delta_kernel:
+    min_delta varints of every length (those of 9 and 10 bytes leave that path), widths on both sides of 24 (up to
+    which a block's sums are taken in 32 bits), of 32 and of 64, streams of several chunks, last blocks of every
+    length, junk in the width bytes of mini-blocks that hold no value, and streams that end within 12 bytes of their
+    last block's start."""
+    rng = np.random.default_rng(40 + num_mini_blocks)
+    per_mini = 128 // num_mini_blocks
+    streams, caps = [], []
+    for k in range(160):
+        n_deltas = int(rng.choice([1, 2, per_mini - 1, per_mini, per_mini + 1, 127, 128, 129, 1000, 128 * 70 + int(rng.integers(0, 128)),
+                                   int(rng.integers(1, 6000))]))
+        deltas = []
+        for at in range(0, n_deltas, 128):
+            length = int(rng.choice([1, 1, 2, 2, 3, 4, 5, 6, 7, 8, 9, 10]))  # bytes of min_delta's varint
+            magnitude = 0 if length == 1 and k % 2 else int(rng.integers(1 << max(7 * length - 8, 0), 1 << min(7 * length - 1, 63)))
+            low = -magnitude if rng.integers(0, 2) else magnitude - 1 if magnitude else 0
+            block = []
+            for m in range(num_mini_blocks):
+                w = int(rng.choice([0, 1, 7, 12, 23, 24, 25, 31, 32, 33, 48, 63, 64]))
+                if k % 3 == 0:
+                    w = min(w, 24)  # whole streams of narrow blocks, and mixed ones
+                rel = [int.from_bytes(rng.bytes(8), "little") >> (64 - w) if w else 0 for _ in range(per_mini)]
+                if w:
+                    rel[int(rng.integers(0, per_mini))] = (1 << w) - 1  # the width is reached
+                block += [low + r for r in rel]
+            block[int(rng.integers(0, 128))] = low  # min_delta is the block's least delta
+            deltas += block
+        deltas = deltas[:n_deltas]
+        values = values_of_deltas(int(rng.integers(-(1 << 63), 1 << 63)), deltas)
+        s = bytearray(encode_delta(values, 128, num_mini_blocks))
+        tail = n_deltas % 128
+        if k % 4 == 1 and tail and (tail - 1) // per_mini + 1 < num_mini_blocks:
+            # the widths of the last block's unused mini-blocks: whatever the writer left there
+            used_minis = (tail - 1) // per_mini + 1
+            # the last block begins where the stream of the values before it ends
+            head = encode_delta(values[:n_deltas + 1 - tail], 128, num_mini_blocks)
+            at = len(head) + len(uleb(n_deltas + 1)) - len(uleb(n_deltas + 1 - tail))
+            while s[at] & 0x80:
+                at += 1
+            at += 1
+            for m in range(used_minis, num_mini_blocks):
+                s[at + m] = int(rng.integers(0, 256))
+        streams.append(bytes(s))
+        caps.append(n_deltas + 1 + int(rng.integers(0, 2)))
+    seen = check_against_oracle(ctx, oracle, streams, caps, pad_front=int(rng.integers(0, 16)))
+    assert seen.get(0, 0) >= 150, seen  # (junk in unused width bytes may be refused: then by both)
+
+
 def test_every_prefix_of_a_stream(ctx, oracle):
     rng = np.random.default_rng(5)
     v = np.cumsum(rng.integers(-1000, 1000, size=300, dtype=np.int64))

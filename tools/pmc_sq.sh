@@ -1,17 +1,22 @@
 #!/bin/bash
-# usage: pmc_sq.sh <tag> [bench args...]: three SQ counter passes over bench.py (PQ2_LIB is honoured), summaries in gpurun_out/pmc_sq_<tag>.txt
-tag=$1; shift
+# Instruction mix per kernel of a bench.py workload: one rocprofv3 pass of SQ counters.
+# usage: pmc_sq.sh <tag> <bench.py arguments>      (prints per kernel and launch: wave instructions by kind, busy cycles)
 R=$GRAFT_REPO_ROOT
+tag=$1; shift
+O=$R/gpurun_out/$tag
+mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-out=$R/gpurun_out/pmc_sq_$tag.txt
-: > $out
-i=0
-for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" \
-           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_WR" \
-           "SQ_INST_CYCLES_SALU SQ_INST_CYCLES_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_WAVES SQ_INSTS_BRANCH SQ_ACTIVE_INST_MISC SQ_INSTS_SENDMSG"; do
-  i=$((i+1))
-  timeout -s KILL 120 rocprofv3 --pmc $set --output-format csv -d $R/gpurun_out/pmc_sq_${tag}_$i -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs "$@" > $R/gpurun_out/pmc_sq_${tag}_$i.log 2>&1 || { echo "pass $i failed" >> $out; tail -n 5 $R/gpurun_out/pmc_sq_${tag}_$i.log >> $out; continue; }
-  python3 $R/tools/pmc_summary.py $R/gpurun_out/pmc_sq_${tag}_$i >> $out
-  rm -rf $R/gpurun_out/pmc_sq_${tag}_$i
-done
-cat $out
+timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_SMEM --output-format csv -d $O/pmc_sq -- python3 $R/bench.py --no-cpu-baseline --no-other-configs --steps 2 --warmup 1 "$@" > $O/pmc_sq.log 2>&1 || exit 1
+cd $R
+python3 - $O <<'PY'
+import csv, glob, sys, collections
+acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
+for f in glob.glob(sys.argv[1] + "/pmc_sq/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        if r["Counter_Name"] == "SQ_INSTS_VALU": n[k] += 1
+for k in sorted(acc):
+    if "pq2::" in k:
+        print(k, "launches", n[k], {c.replace("SQ_", ""): round(v / n[k]) for c, v in sorted(acc[k].items())})
+PY

@@ -1967,7 +1967,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PQ2_DELTA_W
                         const uint32_t next = (e0 | e1) == 0u || over != 0u ? ~0u : at + total;
                         const uint32_t next_pos = __builtin_amdgcn_readfirstlane(next);
                         if (next_pos > limit) break;
-                        if (lane == 0u) ls.brief[listed] = u32x4{b0, b1, widths, (at - chunk_lo) | (behind << 13)};
+                        // (by every lane alike, to one address: a branch on the lane would make a loop of lane masks
+                        // out of this one, whose conditions are all scalar)
+                        ls.brief[listed] = u32x4{b0, b1, widths, (at - chunk_lo) | (behind << 13)};
                         pos = next_pos;
                     }
                     const uint32_t taken = listed == blocks_left ? remaining : listed * 128u;

@@ -250,10 +250,11 @@ typedef struct pq2_dict_ref {
  * `dict.indexes.map(|x| dict.dict.value(x))`, tests/it/read/primitive.rs:99-108).
  * `value_size` is 4 (i32, f32), 8 (i64, f64) or 12 (int96); page i's values go to
  * d_out + descs[i].out_off * value_size (d_out 8-byte aligned).  Where the
- * lookup happens inside the decode kernel (batches that take ring_kernel, pages
- * of at most 16 bits, dictionaries of at most 48 KiB) the indices never exist in
- * device memory; otherwise they pass through a buffer the context owns.  An
- * index that is not below
+ * lookup happens inside the decode kernel (pages of at most 16 bits, in batches
+ * that take ring_kernel with dictionaries of at most 48 KiB, or that one round
+ * of expand_kernel carries: few pages, or pages of dense headers) the indices
+ * never exist in device memory; otherwise they pass through a buffer the
+ * context owns.  An index that is not below
  * dict_len is Error::OutOfSpec in the reference
  * (tests/it/read/dictionary/primitive.rs:20-27): the page gets status
  * PQ2_OUT_OF_SPEC (unless the index stream itself already failed) and the

@@ -26,7 +26,9 @@ hipError_t pq2_launch_parse(const void *pages, uint32_t n_pages, void *resume, u
                             int32_t *status, void *state, uint32_t round, uint32_t max_bits, hipStream_t stream);
 hipError_t pq2_launch_expand(const void *pages, const uint32_t *tile_page, uint32_t tile_start, uint32_t n_tiles,
                              const void *resume, const uint32_t *run_pos, uint32_t round, uint32_t max_bits,
-                             const uint32_t *tile_mask, hipStream_t stream);
+                             const uint32_t *tile_mask, const void *dicts, uint32_t value_words, int32_t *status,
+                             hipStream_t stream);
+uint32_t pq2_expand_dict_max_bits();
 hipError_t pq2_launch_bitunpack(const void *d_packed, uint32_t packed_len, uint32_t num_bits, uint32_t length,
                                 uint32_t *d_out, hipStream_t stream);
 hipError_t pq2_launch_decode(const void *pages, uint32_t n_pages, void *resume, uint32_t *run_pos, int32_t *status,
@@ -168,6 +170,16 @@ struct FusedDict {
     const void *d_nulls = nullptr;  // RingNullable records: the values go to the rows of flat nullable pages
 };
 
+// What pq2_decode_dict_batch_device adds to a batch that does not take ring_kernel: where expand_kernel carries
+// the values (the scout kernels or parse_kernel before it, one round) it looks the indices up itself and writes
+// the dictionaries' values to `d_values` (at out_off * value_words * 4 bytes) instead of indices to d_out; the
+// context's `expand_looked_up` says whether that happened.
+struct ExpandLookup {
+    const void *d_dicts;  // gather descriptors (device)
+    uint32_t value_words;
+    void *d_values;
+};
+
 struct RingNullable {  // must match pq2::RingNullable
     uint64_t bitmap_addr, validity_addr, out_addr, rowdir_addr;
     uint32_t rows, idx_values;
@@ -208,6 +220,7 @@ struct pq2_ctx {
     DevBuf d_indices, d_gather, d_seg_valid;
     DevBuf d_bit_meta;  // pq2_decode_validity_bitmap_batch_device: rows and set bits of every page
     bool fused_declined = false;  // enqueue_batch: the density probe sent a batch with the lookup inside ring_kernel elsewhere
+    bool expand_looked_up = false;  // enqueue_batch: expand_kernel has written dictionary values (ExpandLookup)
     DevBuf d_rowdir;    // pq2_decode_optional_dict_batch_device: the row directories of flat nullable pages (rowdir_kernel)
     // density_kernel (pq2_density.hip): its two counters and the verdict word on the device, the verdict as the host
     // reads it (page-locked, written by the device), the event behind the kernel, a count of its launches
@@ -394,7 +407,8 @@ bool auto_takes_scout(const pq2_page_desc *descs, uint64_t n_pages) {
 int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const pq2_page_desc *descs, uint64_t n_pages,
                       uint32_t *d_out, uint64_t out_values, hipStream_t stream, const FrontJob *front = nullptr,
                       uint32_t min_max_bits = 0, const TileMask *mask = nullptr, const FusedDict *fused = nullptr,
-                      const BitmapOut *bits = nullptr) {
+                      const BitmapOut *bits = nullptr, const ExpandLookup *lookup = nullptr) {
+    ctx->expand_looked_up = false;
     if (n_pages > 0x7fffffffull) return fail(ctx, PQ2_INVALID_PARAMETER, "too many pages in one batch");
     if (n_pages > 0 && !descs) return fail(ctx, PQ2_INVALID_PARAMETER, "descs is NULL");
     // the device-side metadata and the Resume table are shared by consecutive batches: stream order
@@ -491,6 +505,16 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
     const bool split = !per_page && !scout && tiles >= ctx->min_rounded_tiles;
     // Nothing hides the parse of the first part, and the walk of a page takes the same time whatever the batch
     // holds while the expansion grows with it: the larger the batch, the smaller the first part.
+    // the dictionary lookup inside expand_kernel: one round (the statuses are final before the expansion begins)
+    static const bool expand_lookup_allowed = [] {
+        const char *v = std::getenv("PQ2_EXPAND_LOOKUP");
+        return !(v && std::atoi(v) == 0);
+    }();
+    const bool looks_up = lookup && expand_lookup_allowed && !per_page && !split && !front && !mask && !fused && !bits &&
+                          max_bits <= pq2_expand_dict_max_bits();
+    if (looks_up)
+        for (uint64_t i = 0; i < n_pages; ++i)
+            pages[i].out_addr = reinterpret_cast<uint64_t>(lookup->d_values) + descs[i].out_off * lookup->value_words * 4ull;
     double round_split[kRounds - 1];
     std::copy(ctx->round_split, ctx->round_split + kRounds - 1, round_split);
     if (!ctx->split_given && tiles > (1ull << 30) / kTileValues) {
@@ -699,7 +723,7 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
             const uint32_t expected = ctx->last_density_headers;
             ctx->mode = pq2_ctx::kScout;
             st = enqueue_batch(ctx, d_in, in_bytes, descs, n_pages, d_out, out_values, stream, front, min_max_bits, mask,
-                               fused, bits);
+                               fused, bits, lookup);
             ctx->mode = was;
             ctx->last_density_headers = expected;
             return st;
@@ -715,7 +739,8 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
             return st;
         if ((st = stamped(true, stream, [&] {
                  return pq2_launch_expand(d_pages, d_tile_page, 0u, static_cast<uint32_t>(tiles), ctx->d_resume.ptr,
-                                          d_run_pos, 0u, max_bits, d_tile_mask, stream);
+                                          d_run_pos, 0u, max_bits, d_tile_mask, looks_up ? lookup->d_dicts : nullptr,
+                                          looks_up ? lookup->value_words : 0u, d_status, stream);
              })))
             return st;
         rounds = 0;
@@ -733,7 +758,9 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
         if ((st = stamped(true, es[r & 1u], [&] {
                  return pq2_launch_expand(d_pages, d_tile_page, static_cast<uint32_t>(round_start[r]),
                                           static_cast<uint32_t>(round_start[r + 1] - round_start[r]),
-                                          ctx->d_resume.ptr, d_run_pos, r, max_bits, d_tile_mask, es[r & 1u]);
+                                          ctx->d_resume.ptr, d_run_pos, r, max_bits, d_tile_mask,
+                                          looks_up ? lookup->d_dicts : nullptr, looks_up ? lookup->value_words : 0u,
+                                          d_status, es[r & 1u]);
              })))
             return st;
     }
@@ -750,6 +777,10 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
     ctx->last_scout = scout;
     ctx->last_scout_tiles = stiles;
     ctx->last_schedule = fused && fused->d_nulls ? "ring_kernel+dictionary+rows" : fused ? "ring_kernel+dictionary" : bits ? "ring_kernel+bitmap" : ring ? "ring_kernel" : per_page ? "decode_kernel" : scout ? "scout+expand_kernel" : "expand_kernel";
+    if (looks_up) {
+        ctx->expand_looked_up = true;
+        ctx->last_schedule = scout ? "scout+expand_kernel+dictionary" : "expand_kernel+dictionary";
+    }
     return PQ2_OK;
 }
 
@@ -997,27 +1028,47 @@ int32_t pq2_decode_dict_batch_device(pq2_ctx *ctx, const void *d_in, uint64_t in
     if (!fuse) {
         if ((st = reserve(ctx, ctx->d_indices, std::max<uint64_t>(out_values, 1) * sizeof(uint32_t)))) return st;
         d_idx = static_cast<uint32_t *>(ctx->d_indices.ptr);
-        if ((st = enqueue_batch(ctx, d_in, in_bytes, descs, n_pages, d_idx, out_values, stream))) return st;
+        if (n_pages == 0 && (st = enqueue_batch(ctx, d_in, in_bytes, descs, n_pages, d_idx, out_values, stream))) return st;
     }
     if (n_pages > 0) {
         const size_t bytes = n_pages * sizeof(GatherPage);
-        if ((st = stage_block(ctx, bytes, bytes))) return st;
-        GatherPage *g = static_cast<GatherPage *>(ctx->h_gather);
-        uint64_t tiles = 0;
         const uint64_t kGatherTileValues = pq2_gather_tile_values();
-        for (uint64_t i = 0; i < n_pages; ++i) {
-            const pq2_page_desc &d = descs[i];
-            g[i].idx_addr = reinterpret_cast<uint64_t>(d_idx) + d.out_off * sizeof(uint32_t);
-            g[i].out_addr = reinterpret_cast<uint64_t>(d_out) + d.out_off * value_size;
-            g[i].dict_addr = reinterpret_cast<uint64_t>(d_dict) + dicts[i].dict_off;
-            g[i].dict_len = dicts[i].dict_len;
-            g[i].num_values = (fuse ? d.num_bits <= 32 : ctx->host_status[i] == PQ2_OK) ? static_cast<uint32_t>(d.num_values) : 0u;
-            g[i].first_tile = static_cast<uint32_t>(tiles);
-            g[i].reserved = 0;
-            tiles += (uint64_t(g[i].num_values) + kGatherTileValues - 1) / kGatherTileValues;
-        }
-        if ((st = upload_block(ctx, bytes, stream))) return st;
-        if (fuse) {
+        uint64_t tiles = 0;
+        GatherPage *g = nullptr;
+        // (`decoded`: the batch has been through enqueue_batch, which has checked the descriptors)
+        auto stage_dicts = [&](bool decoded) -> int32_t {
+            if (int32_t e = stage_block(ctx, bytes, bytes)) return e;
+            g = static_cast<GatherPage *>(ctx->h_gather);
+            tiles = 0;
+            for (uint64_t i = 0; i < n_pages; ++i) {
+                const pq2_page_desc &d = descs[i];
+                g[i].idx_addr = reinterpret_cast<uint64_t>(d_idx) + d.out_off * sizeof(uint32_t);
+                g[i].out_addr = reinterpret_cast<uint64_t>(d_out) + d.out_off * value_size;
+                g[i].dict_addr = reinterpret_cast<uint64_t>(d_dict) + dicts[i].dict_off;
+                g[i].dict_len = dicts[i].dict_len;
+                g[i].num_values = (decoded ? ctx->host_status[i] == PQ2_OK : d.num_bits <= 32) ? static_cast<uint32_t>(d.num_values) : 0u;
+                g[i].first_tile = static_cast<uint32_t>(tiles);
+                g[i].reserved = 0;
+                tiles += (uint64_t(g[i].num_values) + kGatherTileValues - 1) / kGatherTileValues;
+            }
+            return upload_block(ctx, bytes, stream);
+        };
+        if ((st = stage_dicts(false))) return st;
+        if (!fuse) {
+            // Where expand_kernel carries the values it looks them up as it writes (neither kernel of the other way
+            // then touches a buffer of indices); else -- one workgroup per page, several rounds, indices wider than
+            // the lookup takes -- the batch is decoded into indices and gather_kernel looks them up.
+            const ExpandLookup lookup{ctx->d_gather.ptr, value_size / 4, d_out};
+            if ((st = enqueue_batch(ctx, d_in, in_bytes, descs, n_pages, d_idx, out_values, stream, nullptr, 0, nullptr,
+                                    nullptr, nullptr, &lookup)))
+                return st;
+            if (!ctx->expand_looked_up) {
+                if ((st = stage_dicts(true))) return st;
+                PQ2_HIP(ctx, pq2_launch_gather(ctx->d_gather.ptr, static_cast<uint32_t>(n_pages), static_cast<uint32_t>(tiles),
+                                               value_size / 4, max_dict_bytes, static_cast<int32_t *>(ctx->d_status.ptr),
+                                               stream));
+            }
+        } else {
             // (the descriptors' output offsets are checked against the values; the kernel writes through `dicts`)
             const FusedDict fd{ctx->d_gather.ptr, value_size / 4, static_cast<uint32_t>(max_dict_bytes)};
             if ((st = enqueue_batch(ctx, d_in, in_bytes, descs, n_pages, static_cast<uint32_t *>(d_out), out_values, stream,
@@ -1031,34 +1082,20 @@ int32_t pq2_decode_dict_batch_device(pq2_ctx *ctx, const void *d_in, uint64_t in
                 const pq2_ctx::Mode was = ctx->mode;
                 const uint32_t expected = ctx->last_density_headers;
                 ctx->mode = pq2_ctx::kScout;
-                st = enqueue_batch(ctx, d_in, in_bytes, descs, n_pages, d_idx, out_values, stream);
+                const ExpandLookup lookup{ctx->d_gather.ptr, value_size / 4, d_out};  // (the descriptors are on the device)
+                st = enqueue_batch(ctx, d_in, in_bytes, descs, n_pages, d_idx, out_values, stream, nullptr, 0, nullptr, nullptr,
+                                   nullptr, &lookup);
                 ctx->mode = was;
                 ctx->last_density_headers = expected;
                 if (st) return st;
-                if ((st = stage_block(ctx, bytes, bytes))) return st;
-                g = static_cast<GatherPage *>(ctx->h_gather);
-                tiles = 0;
-                for (uint64_t i = 0; i < n_pages; ++i) {
-                    const pq2_page_desc &d = descs[i];
-                    g[i].idx_addr = reinterpret_cast<uint64_t>(d_idx) + d.out_off * sizeof(uint32_t);
-                    g[i].out_addr = reinterpret_cast<uint64_t>(d_out) + d.out_off * value_size;
-                    g[i].dict_addr = reinterpret_cast<uint64_t>(d_dict) + dicts[i].dict_off;
-                    g[i].dict_len = dicts[i].dict_len;
-                    g[i].num_values = ctx->host_status[i] == PQ2_OK ? static_cast<uint32_t>(d.num_values) : 0u;
-                    g[i].first_tile = static_cast<uint32_t>(tiles);
-                    g[i].reserved = 0;
-                    tiles += (uint64_t(g[i].num_values) + kGatherTileValues - 1) / kGatherTileValues;
+                if (!ctx->expand_looked_up) {
+                    if ((st = stage_dicts(true))) return st;
+                    PQ2_HIP(ctx, pq2_launch_gather(ctx->d_gather.ptr, static_cast<uint32_t>(n_pages),
+                                                   static_cast<uint32_t>(tiles), value_size / 4, max_dict_bytes,
+                                                   static_cast<int32_t *>(ctx->d_status.ptr), stream));
+                    ctx->last_schedule = "scout+expand_kernel+gather_kernel";
                 }
-                if ((st = upload_block(ctx, bytes, stream))) return st;
-                PQ2_HIP(ctx, pq2_launch_gather(ctx->d_gather.ptr, static_cast<uint32_t>(n_pages), static_cast<uint32_t>(tiles),
-                                               value_size / 4, max_dict_bytes, static_cast<int32_t *>(ctx->d_status.ptr),
-                                               stream));
-                ctx->last_schedule = "scout+expand_kernel+gather_kernel";
             }
-        } else {
-            PQ2_HIP(ctx, pq2_launch_gather(ctx->d_gather.ptr, static_cast<uint32_t>(n_pages), static_cast<uint32_t>(tiles),
-                                           value_size / 4, max_dict_bytes, static_cast<int32_t *>(ctx->d_status.ptr),
-                                           stream));
         }
     }
     if (status) return fetch_status(ctx, status, n_pages);

@@ -374,6 +374,63 @@ constexpr uint32_t kStepGroup = PQ2_STEP_GROUP;  // emission steps whose LDS rea
 #endif
 constexpr uint32_t kDirectValues = PQ2_DIRECT_VALUES;  // a pass whose runs are all this short is written run by run (0: never)
 
+// Where expand_block's values go.  ExpandIndexSink stores them as they are (u32, the decode of HybridRleDecoder);
+// ExpandDictSink<kWords> takes them as indices into the page's dictionary, which lies in memory (a few KiB that
+// every tile of the page reads: they stay in the caches), and stores the dictionary's values of kWords dwords each
+// (the consumer loop of a dictionary-encoded page, tests/it/read/primitive.rs:99-108 with
+// PrimitivePageDict::value, tests/it/read/dictionary/primitive.rs:20-27; an index that is not below the
+// dictionary's length is an error of the page, its value is written as zeros).  put4 writes the four positions
+// from p on, which begin at a 16-byte boundary of the output, put1 writes one; mis(): the positions between the
+// 16-byte grid of the output and position 0.
+struct ExpandIndexSink {
+    static constexpr int kMaxBits = 32;
+    out_u32 *out;  // position 0
+    __device__ __forceinline__ uint32_t mis() const { return (uint32_t)(((uintptr_t)out >> 2) & 3u); }
+    __device__ __forceinline__ void put4(const u32x4 v, const int32_t p) { store4(v, out + p); }
+    __device__ __forceinline__ void put1(const uint32_t v, const int32_t p) { out[p] = v; }
+    __device__ __forceinline__ ExpandIndexSink shifted(uint32_t positions) const { return ExpandIndexSink{out + positions}; }
+    __device__ __forceinline__ void absorb(const ExpandIndexSink &) {}
+};
+template <int kWords>
+struct ExpandDictSink {
+    static constexpr int kMaxBits = 16;  // wider indices: through a buffer of indices and gather_kernel
+    typedef __attribute__((address_space(1))) const uint32_t gu32;
+    out_u32 *out;  // the first dword of the value at position 0 (aligned to a whole value: 4, 8 and 4 bytes)
+    gu32 *dict;    // dict_len values of kWords dwords
+    uint32_t dict_len;
+    bool bad;
+    __device__ __forceinline__ uint32_t mis() const {
+        const uint32_t a = (uint32_t)((uintptr_t)out >> 2);
+        return kWords == 1 ? a & 3u : kWords == 2 ? (a >> 1) & 1u : (3u * a) & 3u;
+    }
+    __device__ __forceinline__ void put4(const u32x4 j, const int32_t p) {
+        const uint32_t jj[4] = {j.x, j.y, j.z, j.w};
+        uint32_t v[4 * kWords];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool ok = jj[k] < dict_len;
+            bad |= !ok;
+#pragma unroll
+            for (int c = 0; c < kWords; ++c) v[k * kWords + c] = ok ? dict[(size_t)jj[k] * kWords + c] : 0u;
+        }
+#pragma unroll
+        for (int c = 0; c < kWords; ++c) {
+            const u32x4 o = {v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]};
+            store4(o, out + (ptrdiff_t)p * kWords + 4 * c);
+        }
+    }
+    __device__ __forceinline__ void put1(const uint32_t j, const int32_t p) {
+        const bool ok = j < dict_len;
+        bad |= !ok;
+#pragma unroll
+        for (int c = 0; c < kWords; ++c) out[(ptrdiff_t)p * kWords + c] = ok ? dict[(size_t)j * kWords + c] : 0u;
+    }
+    __device__ __forceinline__ ExpandDictSink shifted(uint32_t positions) const {
+        return ExpandDictSink{out + (size_t)positions * kWords, dict, dict_len, bad};
+    }
+    __device__ __forceinline__ void absorb(const ExpandDictSink &s) { bad |= s.bad; }
+};
+
 // One wave decodes the span [block_start, block_start + block_n) of a page
 // whose width is W (block_n <= kSpanValues).  `tbl` (kTableRuns + 2 entries), `cidx` (kChunkSlots entries) and
 // `win` are the wave's LDS; the window normally holds the block's stream bytes
@@ -400,11 +457,11 @@ constexpr uint32_t kDirectValues = PQ2_DIRECT_VALUES;  // a pass whose runs are 
 //            by value.
 // kCoh: the header list is still being written by another wave (see decode_kernel): its entries are loaded past
 // this compute unit's vector cache.
-template <int W, bool kCoh>
+template <int W, bool kCoh, typename Sink>
 __device__ __forceinline__ void expand_block(const __amdgpu_buffer_rsrc_t rsrc, Window &win, uint2 *tbl,
                                              uint32_t *cidx, const Resume rs, const uint32_t hp_first,
                                              const uint32_t *__restrict__ hdrs, const uint32_t end, const uint32_t n,
-                                             const uint32_t block_start, const uint32_t block_n, out_u32 *out,
+                                             const uint32_t block_start, const uint32_t block_n, Sink &sink,
                                              const uint32_t lane) {
     constexpr uint32_t w = (uint32_t)W;
     constexpr uint32_t kLaneRuns = kTableRuns - 1;               // runs decoded by lanes in one pass
@@ -421,7 +478,7 @@ __device__ __forceinline__ void expand_block(const __amdgpu_buffer_rsrc_t rsrc, 
     // header positions for the next pass, asked for as soon as the pass in hand knows where it ends
     uint32_t ahead_at = kEndPos, ahead_hp = kEndPos;
 
-    const uint32_t mis = (uint32_t)(((uintptr_t)out >> 2) & 3u);  // values between the 16-byte grid and `out`
+    const uint32_t mis = sink.mis();  // values between the 16-byte grid of the output and position 0
     uint32_t lo = 0;                                               // block positions [0, lo) are written
 
     do {  // block_n > 0
@@ -449,11 +506,11 @@ __device__ __forceinline__ void expand_block(const __amdgpu_buffer_rsrc_t rsrc, 
             for (uint32_t q = ((lo + mis) >> 2) + lane; q < q_end; q += 64u) {
                 const int32_t p = (int32_t)(q * 4u) - (int32_t)mis;
                 if (p >= (int32_t)lo && p + 4 <= (int32_t)hi) {
-                    store4(v, out + p);
+                    sink.put4(v, p);
                 } else {
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
-                        if (p + k >= (int32_t)lo && p + k < (int32_t)hi) out[p + k] = payload;
+                        if (p + k >= (int32_t)lo && p + k < (int32_t)hi) sink.put1(payload, p + k);
                 }
             }
         } else {
@@ -515,7 +572,7 @@ __device__ __forceinline__ void expand_block(const __amdgpu_buffer_rsrc_t rsrc, 
                 // more than the values).  The first run's values go one to a lane.
                 if (lane < take0) {
                     const uint32_t p0 = lo + lane;
-                    out[p0] = kind == kRle ? payload : field_at<W>(win.lds, (y0 + p0 * w) & bit_mask);
+                    sink.put1(kind == kRle ? payload : field_at<W>(win.lds, (y0 + p0 * w) & bit_mask), (int32_t)p0);
                 }
                 if (lane < g && start < block_n) {
                     const uint32_t mine = min(run.count, block_n - start);
@@ -525,7 +582,7 @@ __device__ __forceinline__ void expand_block(const __amdgpu_buffer_rsrc_t rsrc, 
                     for (uint32_t k = 0; k < kDirectValues; ++k) f[k] = field_at<W>(win.lds, (bit0 + k * w) & bit_mask);
 #pragma unroll
                     for (uint32_t k = 0; k < kDirectValues; ++k)
-                        if (k < mine) out[start + k] = run.kind == kRle ? run.info : f[k];
+                        if (k < mine) sink.put1(run.kind == kRle ? run.info : f[k], (int32_t)(start + k));
                 }
             } else {
 #pragma unroll
@@ -619,7 +676,7 @@ __device__ __forceinline__ void expand_block(const __amdgpu_buffer_rsrc_t rsrc, 
                             const bool rle = (e[i].x & 1u) != 0u;
                             const uint32_t r = e[i].y;
                             const u32x4 v = {rle ? r : f.x, rle ? r : f.y, rle ? r : f.z, rle ? r : f.w};
-                            if (single & full) store4(v, out + p);
+                            if (single & full) sink.put4(v, p);
                             ragged = ragged | (single & !full);
                         }
                 }
@@ -637,7 +694,7 @@ __device__ __forceinline__ void expand_block(const __amdgpu_buffer_rsrc_t rsrc, 
                         const bool full = p >= (int32_t)lo && p + 4 <= (int32_t)hi;
                         const uint32_t f = field_at<W>(win.lds, (e.y + (uint32_t)pos * w) & bit_mask);
                         if (lane < 4u && single && !full && pos >= (int32_t)lo && pos < (int32_t)hi)
-                            out[pos] = (e.x & 1u) ? e.y : f;
+                            sink.put1((e.x & 1u) ? e.y : f, pos);
                     }
                 }
                 // the chunks in which a run starts: lane r takes the one of run r + 1, value by value.  The chunk's
@@ -672,7 +729,7 @@ __device__ __forceinline__ void expand_block(const __amdgpu_buffer_rsrc_t rsrc, 
                     for (int k = 0; k < 4; ++k) pin(f[k]);
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
-                        if (p + k >= (int32_t)lo && p + k < (int32_t)hi) out[p + k] = (cur[k].x & 1u) ? cur[k].y : f[k];
+                        if (p + k >= (int32_t)lo && p + k < (int32_t)hi) sink.put1((cur[k].x & 1u) ? cur[k].y : f[k], p + k);
                 }
             }
             // ---- next pass (rare: more than 63 runs in the block, or bytes beyond the window) --------------
@@ -712,11 +769,11 @@ __device__ __forceinline__ void expand_block(const __amdgpu_buffer_rsrc_t rsrc, 
 // cannot be waited for without waiting for the store as well; this way no
 // block waits for the stores of the one before it.  `rs4`: lane j holds the
 // Resume entry of the tile's block j.
-template <int W, bool kCoh>
+template <int W, bool kCoh, typename Sink>
 __device__ __forceinline__ void expand_tile(const __amdgpu_buffer_rsrc_t rsrc, Window &win, uint2 *tbl,
                                             uint32_t *cidx, const u32x4 rs4, const uint32_t *__restrict__ hdrs,
                                             const uint32_t end, const uint32_t n, const uint32_t tile_first,
-                                            out_u32 *out, const uint32_t lane, const uint32_t next_from = kEndPos) {
+                                            Sink &sink, const uint32_t lane, const uint32_t next_from = kEndPos) {
     constexpr uint32_t w = (uint32_t)W;
     constexpr uint32_t kSpans = kBlocksPerTile / kSpanBlocks;  // spans per tile
     const uint32_t spans = min(kSpans, (n - tile_first + kSpanValues - 1u) / kSpanValues);
@@ -771,19 +828,22 @@ __device__ __forceinline__ void expand_tile(const __amdgpu_buffer_rsrc_t rsrc, W
         uint32_t hpi = hp[0];
 #pragma unroll
         for (uint32_t k = 1; k < kSpans; ++k) hpi = i == k ? hp[k] : hpi;
+        Sink span_sink = sink.shifted(i * kSpanValues);  // (a span begins at a multiple of four positions: the same grid)
         expand_block<W, kCoh>(rsrc, win, tbl, cidx, resume_of(i), hpi, hdrs, end, n, tile_first + i * kSpanValues,
-                        length_of(i), out + i * kSpanValues, lane);
+                              length_of(i), span_sink, lane);
+        sink.absorb(span_sink);
     }
 }
 
 // One wave decodes tile `tile_first / kTileValues` of page `pg` (`rs4`: lane j holds the Resume entry of the
 // tile's block j) with `win_lds` / `tbl` / `cidx` as its private LDS.
-template <bool kCoh>
-__device__ __forceinline__ void expand_page_tile(const PageDev &pg, const u32x4 rs4, const uint32_t tile_first,
-                                                 const uint32_t *__restrict__ run_pos, uint8_t *win_lds,
-                                                 const uint32_t win_bytes, const uint32_t win_bit_mask, uint2 *tbl,
-                                                 uint32_t *cidx, const uint32_t lane,
-                                                 const uint32_t next_from = kEndPos) {
+// `sink`: position 0 is the tile's first value.
+template <bool kCoh, typename Sink>
+__device__ __forceinline__ void expand_page_tile_into(const PageDev &pg, const u32x4 rs4, const uint32_t tile_first,
+                                                      const uint32_t *__restrict__ run_pos, uint8_t *win_lds,
+                                                      const uint32_t win_bytes, const uint32_t win_bit_mask, uint2 *tbl,
+                                                      uint32_t *cidx, const uint32_t lane, Sink &sink,
+                                                      const uint32_t next_from = kEndPos) {
     const uint32_t n = pg.num_values;
     const uint32_t delta = (uint32_t)(pg.in_addr & 15u);
     const uint32_t end = delta + pg.in_len;
@@ -795,13 +855,13 @@ __device__ __forceinline__ void expand_page_tile(const PageDev &pg, const u32x4 
     win.cap = win_bytes;
     win.bit_mask = win_bit_mask;
     if (lane < 2) tbl[kTableRuns + lane] = make_uint2(kNoRun, 0u);  // read by tbl[j + 1] only
-    out_u32 *const out = (out_u32 *)pg.out_addr + tile_first;
 
     switch (pg.num_bits) {
-#define PQ2_W(N)                                                                                               \
-    case N:                                                                                                    \
-        expand_tile<N, kCoh>(rsrc, win, tbl, cidx, rs4, run_pos + pg.run_base, end, n, tile_first, out, lane, \
-                             next_from);                                                                        \
+#define PQ2_W(N)                                                                                                    \
+    case N:                                                                                                         \
+        if constexpr (N <= Sink::kMaxBits)                                                                          \
+            expand_tile<N, kCoh>(rsrc, win, tbl, cidx, rs4, run_pos + pg.run_base, end, n, tile_first, sink, lane, \
+                                 next_from);                                                                         \
         break;
 #ifdef PQ2_ONLY_W  // single-width build for reading the generated code
         PQ2_W(PQ2_ONLY_W)
@@ -815,15 +875,25 @@ __device__ __forceinline__ void expand_page_tile(const PageDev &pg, const u32x4 
         default: {  // width 0: zeros
             const uint32_t count = min(kTileValues, n - tile_first);
             const u32x4 z = {0u, 0u, 0u, 0u};
-            const uint32_t head = min((4u - (uint32_t)(((uintptr_t)out >> 2) & 3u)) & 3u, count);
-            if (lane < head) out[lane] = 0u;
+            const uint32_t head = min((4u - sink.mis()) & 3u, count);
+            if (lane < head) sink.put1(0u, (int32_t)lane);
             const uint32_t groups = (count - head) >> 2;
-            for (uint32_t g = lane; g < groups; g += 64u) store4(z, out + head + 4u * g);
+            for (uint32_t g = lane; g < groups; g += 64u) sink.put4(z, (int32_t)(head + 4u * g));
             const uint32_t tail = head + 4u * groups;
-            if (lane < count - tail) out[tail + lane] = 0u;
+            if (lane < count - tail) sink.put1(0u, (int32_t)(tail + lane));
             break;
         }
     }
+}
+template <bool kCoh>
+__device__ __forceinline__ void expand_page_tile(const PageDev &pg, const u32x4 rs4, const uint32_t tile_first,
+                                                 const uint32_t *__restrict__ run_pos, uint8_t *win_lds,
+                                                 const uint32_t win_bytes, const uint32_t win_bit_mask, uint2 *tbl,
+                                                 uint32_t *cidx, const uint32_t lane,
+                                                 const uint32_t next_from = kEndPos) {
+    ExpandIndexSink sink{(out_u32 *)pg.out_addr + tile_first};
+    expand_page_tile_into<kCoh>(pg, rs4, tile_first, run_pos, win_lds, win_bytes, win_bit_mask, tbl, cidx, lane, sink,
+                                next_from);
 }
 
 // Selected rows: a page whose `reserved` is not 0 has one bit per tile from word `reserved - 1` of `tile_mask` on;
@@ -863,6 +933,49 @@ __global__ __launch_bounds__(256, PQ2_EXPAND_WAVES) void expand_kernel(const Pag
     uint32_t *cidx = (uint32_t *)(lds + 4u * win_bytes + 32u + 4u * (kTableRuns + 2) * 8u) + wave * kChunkSlots;
     expand_page_tile<false>(pg, rs4, tile_first, run_pos, lds + wave * win_bytes, win_bytes, win_bit_mask, tbl, cidx,
                             lane);
+}
+
+// expand_kernel for pages of dictionary indices whose values are wanted: `pg.out_addr` is where the page's values
+// go, `dicts[page]` names its dictionary (the fields of gather_kernel's descriptor; idx_addr unused), and a page
+// with an index that is not below its dictionary's length gets status PQ2_OUT_OF_SPEC unless it has one already.
+struct ExpandDictRef {  // = GatherPage (declared below, beside gather_kernel)
+    uint64_t idx_addr, out_addr, dict_addr;
+    uint32_t dict_len, num_values, first_tile, reserved;
+};
+template <int kWords>
+__global__ __launch_bounds__(256, PQ2_EXPAND_WAVES) void expand_dict_kernel(const PageDev *__restrict__ pages,
+                                                            const uint32_t *__restrict__ tile_page,
+                                                            const Resume *__restrict__ resume,
+                                                            const uint32_t *__restrict__ run_pos,
+                                                            uint32_t tile_start, uint32_t tile_end, uint32_t round,
+                                                            uint32_t win_bytes, uint32_t win_bit_mask,
+                                                            const uint32_t *__restrict__ tile_mask,
+                                                            const ExpandDictRef *__restrict__ dicts,
+                                                            int32_t *__restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t tile = tile_start + blockIdx.x * 4u + wave;
+    if (tile >= tile_end) return;
+
+    u32x4 rs4 = {0u, 0u, 0u, 0u};
+    if (lane < kBlocksPerTile) rs4 = ((const u32x4 *)resume)[(size_t)tile * kBlocksPerTile + lane];
+    const uint32_t page = tile_page[tile];
+    const PageDev pg = pages[page];
+    const uint32_t tile_first = (pg.round_first(round) + (tile - pg.round_base(round))) * kTileValues;
+    if (tile_first >= pg.num_values) return;
+    if (!tile_wanted(pg, tile_mask, tile_first / kTileValues)) return;
+    if (pg.num_bits > (uint32_t)ExpandDictSink<kWords>::kMaxBits) return;  // (the host sends no such batch here)
+
+    uint2 *tbl = (uint2 *)(lds + 4u * win_bytes + 32u) + wave * (kTableRuns + 2);
+    uint32_t *cidx = (uint32_t *)(lds + 4u * win_bytes + 32u + 4u * (kTableRuns + 2) * 8u) + wave * kChunkSlots;
+    const ExpandDictRef ref = dicts[page];
+    ExpandDictSink<kWords> sink{(out_u32 *)pg.out_addr + (size_t)tile_first * kWords,
+                                (typename ExpandDictSink<kWords>::gu32 *)ref.dict_addr, ref.dict_len, false};
+    expand_page_tile_into<false>(pg, rs4, tile_first, run_pos, lds + wave * win_bytes, win_bytes, win_bit_mask, tbl, cidx,
+                                 lane, sink);
+    if (__ballot(sink.bad) != 0ull && lane == 0u) atomicCAS(&status[page], 0, 1);  // PQ2_OUT_OF_SPEC
 }
 
 // ---------------------------------------------------------------------------
@@ -1077,6 +1190,8 @@ struct GatherPage {  // must match the host's
     uint32_t first_tile;  // batch-wide number of the page's first 4096-value tile
     uint32_t reserved;
 };
+
+static_assert(sizeof(GatherPage) == sizeof(ExpandDictRef), "expand_dict_kernel reads the same descriptors");
 
 constexpr uint32_t kGatherTileValues = 65536;  // values of one page per workgroup of gather_kernel
 
@@ -2254,9 +2369,14 @@ extern "C" hipError_t pq2_launch_probe(const void *pages, uint32_t n_pages, void
 
 // The tiles [tile_start, tile_start + n_tiles) are those of round `round`; `max_bits` is the largest width of
 // a page in the batch: the stream window of a wave is sized for a whole tile of bit-packed values of that width.
+// `dicts` (may be null): the values are dictionary indices of at most pq2_expand_dict_max_bits() bits and what is
+// written are the dictionaries' values of `value_words` dwords (1, 2 or 3) at the pages' out_addr
+// (expand_dict_kernel; `dicts`: one gather descriptor per page, `status`: the pages' statuses).
+extern "C" uint32_t pq2_expand_dict_max_bits() { return (uint32_t)pq2::ExpandDictSink<1>::kMaxBits; }
 extern "C" hipError_t pq2_launch_expand(const void *pages, const uint32_t *tile_page, uint32_t tile_start,
                                         uint32_t n_tiles, const void *resume, const uint32_t *run_pos, uint32_t round,
-                                        uint32_t max_bits, const uint32_t *tile_mask, hipStream_t stream) {
+                                        uint32_t max_bits, const uint32_t *tile_mask, const void *dicts,
+                                        uint32_t value_words, int32_t *status, hipStream_t stream) {
     if (n_tiles == 0) return hipSuccess;
     uint32_t win_bytes = (pq2::kTileValues / 8u) * (max_bits ? max_bits : 1u) + 256u;
     if (win_bytes < 2048u) win_bytes = 2048u;
@@ -2267,9 +2387,24 @@ extern "C" hipError_t pq2_launch_expand(const void *pages, const uint32_t *tile_
     uint32_t pow2 = 2048u;
     while (pow2 < win_bytes) pow2 <<= 1;
     const uint32_t lds_bytes = 4u * win_bytes + 32u + 4u * (pq2::kTableRuns + 2u) * 8u + 4u * pq2::kChunkSlots * 4u;
-    hipLaunchKernelGGL(pq2::expand_kernel, dim3((n_tiles + 3u) / 4u), dim3(256), lds_bytes, stream,
-                       (const pq2::PageDev *)pages, tile_page, (const pq2::Resume *)resume, run_pos, tile_start,
-                       tile_start + n_tiles, round, win_bytes, pow2 * 8u - 1u, tile_mask);
+#define PQ2_EXPAND_DICT(WORDS)                                                                                      \
+    hipLaunchKernelGGL(pq2::expand_dict_kernel<WORDS>, dim3((n_tiles + 3u) / 4u), dim3(256), lds_bytes, stream,       \
+                       (const pq2::PageDev *)pages, tile_page, (const pq2::Resume *)resume, run_pos, tile_start,        \
+                       tile_start + n_tiles, round, win_bytes, pow2 * 8u - 1u, tile_mask,                               \
+                       (const pq2::ExpandDictRef *)dicts, status)
+    if (dicts && value_words == 1u)
+        PQ2_EXPAND_DICT(1);
+    else if (dicts && value_words == 2u)
+        PQ2_EXPAND_DICT(2);
+    else if (dicts && value_words == 3u)
+        PQ2_EXPAND_DICT(3);
+    else if (dicts)
+        return hipErrorInvalidValue;
+    else
+        hipLaunchKernelGGL(pq2::expand_kernel, dim3((n_tiles + 3u) / 4u), dim3(256), lds_bytes, stream,
+                           (const pq2::PageDev *)pages, tile_page, (const pq2::Resume *)resume, run_pos, tile_start,
+                           tile_start + n_tiles, round, win_bytes, pow2 * 8u - 1u, tile_mask);
+#undef PQ2_EXPAND_DICT
     return hipGetLastError();
 }
 

@@ -125,6 +125,8 @@ def test_lookup_inside_the_decode_kernel(ctx, oracle, value_size):
     got, status = run(ctx, data, descs, out_values, dict_bytes, np.array(refs, dtype=DICT_REF_DTYPE), value_size)
     if ctx.last_schedule().startswith("ring_kernel"):
         assert ctx.last_schedule() == "ring_kernel+dictionary"
+    elif "expand_kernel" in ctx.last_schedule():  # one round of expand_kernel: the lookup happens inside it as well
+        assert ctx.last_schedule() in ("scout+expand_kernel+dictionary", "expand_kernel+dictionary")
     covered = np.zeros(out_values, dtype=bool)
     seen = set()
     for k, (d, (stream, w, n, table)) in enumerate(zip(descs, pages)):
@@ -197,8 +199,8 @@ def test_bad_arguments(ctx):
 
 def test_dense_headers_send_a_dictionary_batch_round_the_lookup_inside(oracle):
     """200 dictionary pages of short runs (a header per six values): the default schedule looks at the headers, does not
-    give the batch to ring_kernel with the lookup inside, and decodes to indices through the scout kernels with
-    gather_kernel behind; 200 pages of long runs stay with the lookup inside.  Same values either way."""
+    give the batch to ring_kernel with the lookup inside, and sends it through the scout kernels with the lookup
+    inside expand_kernel; 200 pages of long runs stay with ring_kernel.  Same values either way."""
     from parquet2_amd import Context
 
     rng = np.random.default_rng(17)
@@ -221,7 +223,7 @@ def test_dense_headers_send_a_dictionary_batch_round_the_lookup_inside(oracle):
             refs["dict_len"] = len(table)
             got, status = run(ctx, data, descs, out_values, table.view(np.uint8).reshape(-1), refs, 4)
             assert (status == OK).all()
-            assert ("gather_kernel" in ctx.last_schedule()) == (kind == "short"), (kind, ctx.last_schedule())
+            assert (ctx.last_schedule() == "scout+expand_kernel+dictionary") == (kind == "short"), (kind, ctx.last_schedule())
             for p in range(200):
                 o = int(descs[p]["out_off"])
                 assert np.array_equal(got[o:o + n, 0], want[p]), (kind, p)

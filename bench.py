@@ -23,7 +23,9 @@ JSON line with the same fields):
 With no --workload the line is the default workload's, and it carries the other single-GPU BASELINE configs under
 "other_configs" (definition levels 10 000 x 65 536; adversarial pages at widths 3 / 17 / 31; 64 index pages, the batch
 size SURVEY quotes config 2 on; the 75 / 25 page mix of configs[4]; bit-unpack at every width), each with its step
-time, rate, dominant kernel and roofline fraction.  --no-other-configs leaves them out (A/B runs, counter passes).
+time, rate, dominant kernel and roofline fraction, and under "next_rows" one measurement each of the entry points
+either side of the main decode (DELTA_BINARY_PACKED streams, flat nullable dictionary pages, a batch of few
+dictionary pages with their values).  --no-other-configs leaves both out (A/B runs, counter passes).
 
 The K timed steps run with nothing but the decoder's own work in the stream: `value` and `ms_per_step` are theirs.
 The duration of the dominant kernel (`roofline`) is taken with HIP events over a second run of the same K steps
@@ -578,6 +580,110 @@ def run_pages(a, env):
     return result
 
 
+def bench_next_rows(ctx, dev, stream):
+    """The entry points either side of the main decode, one measurement each (one GPU, inputs resident, what the
+    tools under tools/ measure at length): DELTA_BINARY_PACKED streams into i64, flat nullable dictionary pages into
+    values + validity, and a batch of few dictionary pages with the lookup inside expand_kernel."""
+    from parquet2_amd import DICT_REF_DTYPE, PAGE_DESC_DTYPE
+    from parquet2_amd.encoding import delta_bitpacked
+
+    rows_out = []
+    # -- delta_bitpacked::Decoder: 4096 streams of 65 537 values, deltas of 10 bits (the library's encoder: blocks of
+    #    128 values in one mini-block, the reference's layout, src/encoding/delta_bitpacked/encoder.rs:11-78)
+    rng = np.random.default_rng(1)
+    n_streams, n_values = 4096, 65537
+    v = np.cumsum(rng.integers(0, 1 << 10, size=n_values, dtype=np.int64))
+    one = np.frombuffer(delta_bitpacked.encode(v), dtype=np.uint8)
+    stride = (one.size + 15) & ~15
+    blob = np.zeros((n_streams, stride), dtype=np.uint8)
+    blob[:, :one.size] = one
+    descs = np.zeros(n_streams, dtype=PAGE_DESC_DTYPE)
+    descs["in_off"] = np.arange(n_streams, dtype=np.uint64) * stride
+    descs["in_len"] = one.size
+    descs["num_values"] = n_values
+    descs["out_off"] = np.arange(n_streams, dtype=np.uint64) * n_values
+    d_in = torch.from_numpy(blob.reshape(-1)).to(dev)
+    d_out = torch.zeros(n_streams * n_values, dtype=torch.int64, device=dev)
+    best = 1e9
+    for r in range(6):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        status, counts, consumed = ctx.delta_bitpacked_decode_batch_device(d_in.data_ptr(), blob.size, descs,
+                                                                          d_out.data_ptr(), d_out.numel())
+        dt = time.perf_counter() - t0
+        if r:
+            best = min(best, dt)
+    got = d_out.view(n_streams, n_values)
+    ok = bool((status == 0).all() and (counts == n_values).all() and (consumed == one.size).all() and
+              (got[0].cpu().numpy() == v).all() and (got[-1].cpu().numpy() == v).all())
+    rows_out.append({"entry_point": "pq2_delta_bitpacked_decode_batch_device",
+                     "workload": "%d DELTA_BINARY_PACKED streams x %d values, 10-bit deltas, blocks of 128 / 1 mini-block" % (n_streams, n_values),
+                     "ms_per_call": round(best * 1e3, 4), "includes": "the download of the per-stream results",
+                     "values_per_second_G": round(n_streams * n_values / best / 1e9, 1),
+                     "stream_plus_value_GBps": round(n_streams * (one.size + 8 * n_values) / best / 1e9, 1),
+                     "parity_gate": "generator values, first and last stream: " + ("equal" if ok else "DIFFERENT")})
+    del d_in, d_out, got
+    torch.cuda.empty_cache()
+
+    # -- flat nullable dictionary pages: 4096 pages x 2^18 rows, levels as configs[2], 12-bit indices, 4-byte values
+    pages_n, rows, value_size = 4096, 1 << 18, 4
+    distinct = [(synth.def_levels_page(synth.seed_for(3, p), rows), synth.dict_page(synth.seed_for(2, p), rows, 12))
+                for p in range(8)]
+    chunks, at, place = [], 0, []
+    for (ds, _), (xs, _) in distinct:
+        place.append((at, len(ds), at + len(ds), len(xs)))
+        chunks += [ds, xs]
+        at += len(ds) + len(xs)
+        chunks.append(np.zeros((-at) % 16, dtype=np.uint8))
+        at += (-at) % 16
+    one = np.concatenate(chunks + [np.zeros(16, dtype=np.uint8)])
+    d_in = torch.from_numpy(one).to(dev).repeat((pages_n + 7) // 8)
+    defs = np.zeros(pages_n, dtype=PAGE_DESC_DTYPE)
+    idxs = np.zeros(pages_n, dtype=PAGE_DESC_DTYPE)
+    for i in range(pages_n):
+        o, base = place[i % 8], (i // 8) * one.size
+        defs[i] = (base + o[0], o[1], 1, rows, i * rows)
+        idxs[i] = (base + o[2], o[3], 12, rows, 0)
+    table = torch.randint(-2**31, 2**31 - 1, (4096,), dtype=torch.int32, device=dev)
+    refs = np.zeros(pages_n, dtype=DICT_REF_DTYPE)
+    refs["dict_len"] = 4096
+    d_out = torch.empty(pages_n * rows, dtype=torch.int32, device=dev)
+    d_val = torch.empty(pages_n * rows, dtype=torch.uint8, device=dev)
+    levels_max = np.ones(pages_n, np.uint32)
+
+    def step(want=False):
+        return ctx.decode_optional_dict_batch_device(d_in.data_ptr(), d_in.numel(), defs, idxs, levels_max,
+                                                     table.data_ptr(), table.numel() * 4, refs, value_size,
+                                                     d_out.data_ptr(), d_val.data_ptr(), pages_n * rows, stream,
+                                                     want_status=want)
+
+    ok = bool((step(True) == 0).all())
+    lv, ix = distinct[3][0][1], distinct[3][1][1]
+    valid = lv == 1
+    exp = torch.zeros(rows, dtype=torch.int32)
+    exp[torch.from_numpy(valid)] = table.cpu()[torch.from_numpy(ix[:int(valid.sum())].astype(np.int64))]
+    ok = ok and torch.equal(d_out.view(pages_n, rows)[3].cpu(), exp) and \
+        torch.equal(d_val.view(pages_n, rows)[3].cpu(), torch.from_numpy(valid.astype(np.uint8)))
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    steps = 20
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / steps
+    rows_out.append({"entry_point": "pq2_decode_optional_dict_batch_device",
+                     "workload": "%d flat nullable dictionary pages x %d rows, one-bit levels with 5 %% nulls in bursts, 12-bit indices, %d-byte values" % (pages_n, rows, value_size),
+                     "ms_per_step": round(el * 1e3, 4), "schedule": ctx.last_schedule(),
+                     "rows_per_second_G": round(pages_n * rows / el / 1e9, 1),
+                     "value_plus_validity_GBps": round(pages_n * rows * (value_size + 1) / el / 1e9, 1),
+                     "parity_gate": "generator values and validity, one page: " + ("equal" if ok else "DIFFERENT")})
+    del d_in, d_out, d_val
+    torch.cuda.empty_cache()
+    return rows_out
+
+
 def brief(line):
     """What other_configs keeps of a workload's line."""
     r = line["roofline"]
@@ -664,6 +770,17 @@ def main():
             lines.append(brief(bench_bitunpack(b, dev, ctx, stream)))
         if result is not None:
             result["other_configs"] = lines
+        if world == 1 and result is not None:
+            # beside the BASELINE configs: the entry points either side of the main decode
+            torch.cuda.empty_cache()
+            next_rows = bench_next_rows(ctx, dev, stream)
+            torch.cuda.empty_cache()
+            line = run_pages(sub(workload="dict", pages=64, gather_bytes=4), env)
+            if line is not None:
+                next_rows.append({"entry_point": "pq2_decode_dict_batch_device", "workload": line["config"]["workload"],
+                                  "ms_per_step": line["ms_per_step"], "values_per_second_G": line.get("values_per_second"),
+                                  "schedule": ctx.last_schedule()})
+            result["next_rows"] = next_rows
     if result is not None:
         print(json.dumps(result), flush=True)
     ctx.close()

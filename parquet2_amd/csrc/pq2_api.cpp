@@ -512,9 +512,15 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
     }();
     const bool looks_up = lookup && expand_lookup_allowed && !per_page && !split && !front && !mask && !fused && !bits &&
                           max_bits <= pq2_expand_dict_max_bits();
-    if (looks_up)
+    if (looks_up) {
         for (uint64_t i = 0; i < n_pages; ++i)
             pages[i].out_addr = reinterpret_cast<uint64_t>(lookup->d_values) + descs[i].out_off * lookup->value_words * 4ull;
+    } else if (lookup) {
+        // the indices go to the context's buffer (the caller passes no d_out), which exists only where it is needed
+        if ((st = reserve(ctx, ctx->d_indices, std::max<uint64_t>(out_values, 1) * sizeof(uint32_t)))) return st;
+        for (uint64_t i = 0; i < n_pages; ++i)
+            pages[i].out_addr = reinterpret_cast<uint64_t>(ctx->d_indices.ptr) + descs[i].out_off * sizeof(uint32_t);
+    }
     double round_split[kRounds - 1];
     std::copy(ctx->round_split, ctx->round_split + kRounds - 1, round_split);
     if (!ctx->split_given && tiles > (1ull << 30) / kTileValues) {
@@ -1025,11 +1031,8 @@ int32_t pq2_decode_dict_batch_device(pq2_ctx *ctx, const void *d_in, uint64_t in
     const bool fuse = fused_allowed && n_pages > 0 && takes_ring(ctx, n_pages) && max_bits <= pq2_ring_dict_max_bits() &&
                       max_dict_bytes <= pq2_ring_dict_max_bytes();
     uint32_t *d_idx = nullptr;
-    if (!fuse) {
-        if ((st = reserve(ctx, ctx->d_indices, std::max<uint64_t>(out_values, 1) * sizeof(uint32_t)))) return st;
-        d_idx = static_cast<uint32_t *>(ctx->d_indices.ptr);
-        if (n_pages == 0 && (st = enqueue_batch(ctx, d_in, in_bytes, descs, n_pages, d_idx, out_values, stream))) return st;
-    }
+    if (!fuse && n_pages == 0 && (st = enqueue_batch(ctx, d_in, in_bytes, descs, n_pages, d_idx, out_values, stream)))
+        return st;
     if (n_pages > 0) {
         const size_t bytes = n_pages * sizeof(GatherPage);
         const uint64_t kGatherTileValues = pq2_gather_tile_values();
@@ -1063,6 +1066,7 @@ int32_t pq2_decode_dict_batch_device(pq2_ctx *ctx, const void *d_in, uint64_t in
                                     nullptr, nullptr, &lookup)))
                 return st;
             if (!ctx->expand_looked_up) {
+                d_idx = static_cast<uint32_t *>(ctx->d_indices.ptr);
                 if ((st = stage_dicts(true))) return st;
                 PQ2_HIP(ctx, pq2_launch_gather(ctx->d_gather.ptr, static_cast<uint32_t>(n_pages), static_cast<uint32_t>(tiles),
                                                value_size / 4, max_dict_bytes, static_cast<int32_t *>(ctx->d_status.ptr),
@@ -1077,8 +1081,6 @@ int32_t pq2_decode_dict_batch_device(pq2_ctx *ctx, const void *d_in, uint64_t in
             if (ctx->fused_declined) {
                 // The pages' headers are too dense for one walking wave per page (density_kernel): the scout kernels
                 // decode the batch into indices and gather_kernel looks them up, as for a batch of few pages.
-                if ((st = reserve(ctx, ctx->d_indices, std::max<uint64_t>(out_values, 1) * sizeof(uint32_t)))) return st;
-                d_idx = static_cast<uint32_t *>(ctx->d_indices.ptr);
                 const pq2_ctx::Mode was = ctx->mode;
                 const uint32_t expected = ctx->last_density_headers;
                 ctx->mode = pq2_ctx::kScout;
@@ -1089,6 +1091,7 @@ int32_t pq2_decode_dict_batch_device(pq2_ctx *ctx, const void *d_in, uint64_t in
                 ctx->last_density_headers = expected;
                 if (st) return st;
                 if (!ctx->expand_looked_up) {
+                    d_idx = static_cast<uint32_t *>(ctx->d_indices.ptr);
                     if ((st = stage_dicts(true))) return st;
                     PQ2_HIP(ctx, pq2_launch_gather(ctx->d_gather.ptr, static_cast<uint32_t>(n_pages),
                                                    static_cast<uint32_t>(tiles), value_size / 4, max_dict_bytes,

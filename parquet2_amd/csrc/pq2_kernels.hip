@@ -773,10 +773,13 @@ template <int W, bool kCoh, typename Sink>
 __device__ __forceinline__ void expand_tile(const __amdgpu_buffer_rsrc_t rsrc, Window &win, uint2 *tbl,
                                             uint32_t *cidx, const u32x4 rs4, const uint32_t *__restrict__ hdrs,
                                             const uint32_t end, const uint32_t n, const uint32_t tile_first,
-                                            Sink &sink, const uint32_t lane, const uint32_t next_from = kEndPos) {
+                                            Sink &sink, const uint32_t lane, const uint32_t next_from = kEndPos,
+                                            const uint32_t span_lo = 0u, const uint32_t span_hi = 0xffffffffu) {
     constexpr uint32_t w = (uint32_t)W;
     constexpr uint32_t kSpans = kBlocksPerTile / kSpanBlocks;  // spans per tile
-    const uint32_t spans = min(kSpans, (n - tile_first + kSpanValues - 1u) / kSpanValues);
+    // (the wave takes the tile's spans [span_lo, span_hi): all of them, or one where a batch of few tiles gives
+    // every span a wave of its own)
+    const uint32_t spans = min(min(kSpans, span_hi), (n - tile_first + kSpanValues - 1u) / kSpanValues);
     // lane j holds the Resume entry of block j; span i starts with block i * kSpanBlocks
     auto resume_of = [&](uint32_t i) {
         Resume r;
@@ -791,7 +794,7 @@ __device__ __forceinline__ void expand_tile(const __amdgpu_buffer_rsrc_t rsrc, W
     // lane j = i * kSpanBlocks: does span i take bytes from the stream, and from where on
     uint32_t from = kEndPos;
     bool alone = true;
-    if (lane < kBlocksPerTile && lane % kSpanBlocks == 0u && lane / kSpanBlocks < spans) {
+    if (lane < kBlocksPerTile && lane % kSpanBlocks == 0u && lane / kSpanBlocks < spans && lane / kSpanBlocks >= span_lo) {
         const uint32_t kind = rs4.y >> 31;
         alone = (rs4.y & kRemMask) >= length_of(lane / kSpanBlocks);  // the first run covers the whole span
         // bit-packed: the group that holds the span's first value; RLE: the byte behind the run
@@ -803,7 +806,7 @@ __device__ __forceinline__ void expand_tile(const __amdgpu_buffer_rsrc_t rsrc, W
 #pragma unroll
     for (uint32_t i = 0; i < kSpans; ++i) {
         hp[i] = kEndPos;
-        const bool wanted = i < spans && !__builtin_amdgcn_readlane((uint32_t)alone, i * kSpanBlocks);
+        const bool wanted = i < spans && i >= span_lo && !__builtin_amdgcn_readlane((uint32_t)alone, i * kSpanBlocks);
         if (wanted && lane < 63u) {
             const uint32_t *at = &hdrs[__builtin_amdgcn_readlane(rs4.x, i * kSpanBlocks) + 1u + lane];
             hp[i] = kCoh ? load_coherent(at) : *at;
@@ -817,14 +820,14 @@ __device__ __forceinline__ void expand_tile(const __amdgpu_buffer_rsrc_t rsrc, W
         if (fi != kEndPos) tile_from = fi, first_needing = i;
     }
     if (tile_from != kEndPos) {
-        const uint32_t values = min(kTileValues - first_needing * kSpanValues, n - (tile_first + first_needing * kSpanValues));
+        const uint32_t values = min((spans - first_needing) * kSpanValues, n - (tile_first + first_needing * kSpanValues));
         // the estimate assumes bit-packed values throughout; where the next tile's bytes begin, if known, bounds
         // it (this tile's last value lies in the group before that byte or in the one that holds it)
         uint32_t bytes = ((values * w) >> 3) + (values >> 3) + 128u;
         if (next_from != kEndPos && next_from >= tile_from) bytes = min(bytes, next_from - tile_from + w + 16u);
         win.fill(rsrc, tile_from, bytes, lane);
     }
-    for (uint32_t i = 0; i < spans; ++i) {
+    for (uint32_t i = span_lo; i < spans; ++i) {
         uint32_t hpi = hp[0];
 #pragma unroll
         for (uint32_t k = 1; k < kSpans; ++k) hpi = i == k ? hp[k] : hpi;
@@ -843,7 +846,8 @@ __device__ __forceinline__ void expand_page_tile_into(const PageDev &pg, const u
                                                       const uint32_t *__restrict__ run_pos, uint8_t *win_lds,
                                                       const uint32_t win_bytes, const uint32_t win_bit_mask, uint2 *tbl,
                                                       uint32_t *cidx, const uint32_t lane, Sink &sink,
-                                                      const uint32_t next_from = kEndPos) {
+                                                      const uint32_t next_from = kEndPos, const uint32_t span_lo = 0u,
+                                                      const uint32_t span_hi = 0xffffffffu) {
     const uint32_t n = pg.num_values;
     const uint32_t delta = (uint32_t)(pg.in_addr & 15u);
     const uint32_t end = delta + pg.in_len;
@@ -861,7 +865,7 @@ __device__ __forceinline__ void expand_page_tile_into(const PageDev &pg, const u
     case N:                                                                                                         \
         if constexpr (N <= Sink::kMaxBits)                                                                          \
             expand_tile<N, kCoh>(rsrc, win, tbl, cidx, rs4, run_pos + pg.run_base, end, n, tile_first, sink, lane, \
-                                 next_from);                                                                         \
+                                 next_from, span_lo, span_hi);                                                       \
         break;
 #ifdef PQ2_ONLY_W  // single-width build for reading the generated code
         PQ2_W(PQ2_ONLY_W)
@@ -872,7 +876,8 @@ __device__ __forceinline__ void expand_page_tile_into(const PageDev &pg, const u
         PQ2_W(25) PQ2_W(26) PQ2_W(27) PQ2_W(28) PQ2_W(29) PQ2_W(30) PQ2_W(31) PQ2_W(32)
 #endif
 #undef PQ2_W
-        default: {  // width 0: zeros
+        default: {  // width 0: zeros (by the wave that has the tile's first span)
+            if (span_lo != 0u) break;
             const uint32_t count = min(kTileValues, n - tile_first);
             const u32x4 z = {0u, 0u, 0u, 0u};
             const uint32_t head = min((4u - sink.mis()) & 3u, count);
@@ -906,6 +911,9 @@ __device__ __forceinline__ bool tile_wanted(const PageDev &pg, const uint32_t *_
 #ifndef PQ2_EXPAND_WAVES
 #define PQ2_EXPAND_WAVES 5
 #endif
+#ifndef PQ2_EXPAND_PER_SPAN_TILES
+#define PQ2_EXPAND_PER_SPAN_TILES 8192  // launches of at most this many tiles give every span of a tile its own wave
+#endif
 // One workgroup = four waves = four consecutive tiles of the round (tiles [tile_start, tile_end) in the batch-wide
 // numbering).  Dynamic LDS: four windows of `win_bytes` each, 32 spare bytes, four run tables, four chunk indexes.
 __global__ __launch_bounds__(256, PQ2_EXPAND_WAVES) void expand_kernel(const PageDev *__restrict__ pages,
@@ -914,25 +922,30 @@ __global__ __launch_bounds__(256, PQ2_EXPAND_WAVES) void expand_kernel(const Pag
                                                        const uint32_t *__restrict__ run_pos,
                                                        uint32_t tile_start, uint32_t tile_end, uint32_t round,
                                                        uint32_t win_bytes, uint32_t win_bit_mask,
-                                                       const uint32_t *__restrict__ tile_mask) {
+                                                       const uint32_t *__restrict__ tile_mask, uint32_t per_span) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t tile = tile_start + blockIdx.x * 4u + wave;
+    // per_span: a wave for every span of a tile (batches of few tiles: more waves to hide each other's waits)
+    constexpr uint32_t kSpans = kBlocksPerTile / kSpanBlocks;
+    const uint32_t unit = blockIdx.x * 4u + wave;
+    const uint32_t tile = tile_start + (per_span ? unit / kSpans : unit);
+    const uint32_t span_lo = per_span ? unit % kSpans : 0u, span_hi = per_span ? span_lo + 1u : 0xffffffffu;
     if (tile >= tile_end) return;
 
     u32x4 rs4 = {0u, 0u, 0u, 0u};
     if (lane < kBlocksPerTile) rs4 = ((const u32x4 *)resume)[(size_t)tile * kBlocksPerTile + lane];
     const PageDev pg = pages[tile_page[tile]];
     const uint32_t tile_first = (pg.round_first(round) + (tile - pg.round_base(round))) * kTileValues;
-    if (tile_first >= pg.num_values) return;
+    if (tile_first + span_lo * kSpanValues >= pg.num_values) return;
     if (!tile_wanted(pg, tile_mask, tile_first / kTileValues)) return;
 
     uint2 *tbl = (uint2 *)(lds + 4u * win_bytes + 32u) + wave * (kTableRuns + 2);
     uint32_t *cidx = (uint32_t *)(lds + 4u * win_bytes + 32u + 4u * (kTableRuns + 2) * 8u) + wave * kChunkSlots;
-    expand_page_tile<false>(pg, rs4, tile_first, run_pos, lds + wave * win_bytes, win_bytes, win_bit_mask, tbl, cidx,
-                            lane);
+    ExpandIndexSink sink{(out_u32 *)pg.out_addr + tile_first};
+    expand_page_tile_into<false>(pg, rs4, tile_first, run_pos, lds + wave * win_bytes, win_bytes, win_bit_mask, tbl, cidx,
+                                 lane, sink, kEndPos, span_lo, span_hi);
 }
 
 // expand_kernel for pages of dictionary indices whose values are wanted: `pg.out_addr` is where the page's values
@@ -951,12 +964,15 @@ __global__ __launch_bounds__(256, PQ2_EXPAND_WAVES) void expand_dict_kernel(cons
                                                             uint32_t win_bytes, uint32_t win_bit_mask,
                                                             const uint32_t *__restrict__ tile_mask,
                                                             const ExpandDictRef *__restrict__ dicts,
-                                                            int32_t *__restrict__ status) {
+                                                            int32_t *__restrict__ status, uint32_t per_span) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t tile = tile_start + blockIdx.x * 4u + wave;
+    constexpr uint32_t kSpans = kBlocksPerTile / kSpanBlocks;
+    const uint32_t unit = blockIdx.x * 4u + wave;
+    const uint32_t tile = tile_start + (per_span ? unit / kSpans : unit);
+    const uint32_t span_lo = per_span ? unit % kSpans : 0u, span_hi = per_span ? span_lo + 1u : 0xffffffffu;
     if (tile >= tile_end) return;
 
     u32x4 rs4 = {0u, 0u, 0u, 0u};
@@ -964,7 +980,7 @@ __global__ __launch_bounds__(256, PQ2_EXPAND_WAVES) void expand_dict_kernel(cons
     const uint32_t page = tile_page[tile];
     const PageDev pg = pages[page];
     const uint32_t tile_first = (pg.round_first(round) + (tile - pg.round_base(round))) * kTileValues;
-    if (tile_first >= pg.num_values) return;
+    if (tile_first + span_lo * kSpanValues >= pg.num_values) return;
     if (!tile_wanted(pg, tile_mask, tile_first / kTileValues)) return;
     if (pg.num_bits > (uint32_t)ExpandDictSink<kWords>::kMaxBits) return;  // (the host sends no such batch here)
 
@@ -974,7 +990,7 @@ __global__ __launch_bounds__(256, PQ2_EXPAND_WAVES) void expand_dict_kernel(cons
     ExpandDictSink<kWords> sink{(out_u32 *)pg.out_addr + (size_t)tile_first * kWords,
                                 (typename ExpandDictSink<kWords>::gu32 *)ref.dict_addr, ref.dict_len, false};
     expand_page_tile_into<false>(pg, rs4, tile_first, run_pos, lds + wave * win_bytes, win_bytes, win_bit_mask, tbl, cidx,
-                                 lane, sink);
+                                 lane, sink, kEndPos, span_lo, span_hi);
     if (__ballot(sink.bad) != 0ull && lane == 0u) atomicCAS(&status[page], 0, 1);  // PQ2_OUT_OF_SPEC
 }
 
@@ -2387,11 +2403,18 @@ extern "C" hipError_t pq2_launch_expand(const void *pages, const uint32_t *tile_
     uint32_t pow2 = 2048u;
     while (pow2 < win_bytes) pow2 <<= 1;
     const uint32_t lds_bytes = 4u * win_bytes + 32u + 4u * (pq2::kTableRuns + 2u) * 8u + 4u * pq2::kChunkSlots * 4u;
+    // a batch of few tiles: a wave for every span of a tile
+    static const uint32_t per_span_most = [] {
+        const char *v = getenv("PQ2_EXPAND_PER_SPAN_TILES");
+        return v ? (uint32_t)atoi(v) : PQ2_EXPAND_PER_SPAN_TILES;
+    }();
+    const uint32_t per_span = n_tiles <= per_span_most ? 1u : 0u;
+    const uint32_t units = per_span ? n_tiles * (pq2::kBlocksPerTile / pq2::kSpanBlocks) : n_tiles;
 #define PQ2_EXPAND_DICT(WORDS)                                                                                      \
-    hipLaunchKernelGGL(pq2::expand_dict_kernel<WORDS>, dim3((n_tiles + 3u) / 4u), dim3(256), lds_bytes, stream,       \
+    hipLaunchKernelGGL(pq2::expand_dict_kernel<WORDS>, dim3((units + 3u) / 4u), dim3(256), lds_bytes, stream,         \
                        (const pq2::PageDev *)pages, tile_page, (const pq2::Resume *)resume, run_pos, tile_start,        \
                        tile_start + n_tiles, round, win_bytes, pow2 * 8u - 1u, tile_mask,                               \
-                       (const pq2::ExpandDictRef *)dicts, status)
+                       (const pq2::ExpandDictRef *)dicts, status, per_span)
     if (dicts && value_words == 1u)
         PQ2_EXPAND_DICT(1);
     else if (dicts && value_words == 2u)
@@ -2401,9 +2424,9 @@ extern "C" hipError_t pq2_launch_expand(const void *pages, const uint32_t *tile_
     else if (dicts)
         return hipErrorInvalidValue;
     else
-        hipLaunchKernelGGL(pq2::expand_kernel, dim3((n_tiles + 3u) / 4u), dim3(256), lds_bytes, stream,
+        hipLaunchKernelGGL(pq2::expand_kernel, dim3((units + 3u) / 4u), dim3(256), lds_bytes, stream,
                            (const pq2::PageDev *)pages, tile_page, (const pq2::Resume *)resume, run_pos, tile_start,
-                           tile_start + n_tiles, round, win_bytes, pow2 * 8u - 1u, tile_mask);
+                           tile_start + n_tiles, round, win_bytes, pow2 * 8u - 1u, tile_mask, per_span);
 #undef PQ2_EXPAND_DICT
     return hipGetLastError();
 }

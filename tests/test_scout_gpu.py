@@ -108,6 +108,40 @@ def test_adversarial_batch_every_schedule(any_schedule, oracle, w):
         assert st_o == OK and (exp == pages[p][1]).all()
 
 
+@pytest.mark.parametrize("mode", ["tile", "scout"])
+def test_more_tiles_than_get_a_wave_per_span(oracle, mode):
+    """expand_kernel gives every span of a tile its own wave in launches of at most 8192 tiles (which is what nearly
+    every other test launches) and a wave per tile beyond: 40 pages of 2^20 + 1 values (10 280 tiles), mixed runs and
+    short runs, every value against the oracle."""
+    import torch
+
+    n = (1 << 20) + 1
+    distinct = [synth.dict_page(synth.seed_for(2, 900 + p), n, 12)[0] for p in range(3)] + \
+               [synth.adversarial(synth.seed_for(4, 900), n, 12)[0]]
+    want = []
+    for s in distinct:
+        st, exp = oracle.hybrid_rle_decode(s, 12, n)
+        assert st == OK
+        want.append(exp)
+    batch = synth.PageBatch()
+    for p in range(40):
+        batch.add(distinct[p % 4], 12, n)
+    data, descs, out_values = batch.finish()
+    ctx = _context(mode)
+    try:
+        d_in = torch.from_numpy(data).cuda()
+        d_out = torch.full((out_values,), -1, dtype=torch.int32, device="cuda")
+        st = ctx.decode_batch_device(d_in.data_ptr(), d_in.numel(), descs, d_out.data_ptr(), out_values,
+                                     torch.cuda.current_stream().cuda_stream)
+        assert (st == OK).all() and "expand_kernel" in ctx.last_schedule()
+        got = d_out.cpu().numpy().view(np.uint32)
+        for p in range(40):
+            o = int(descs[p]["out_off"])
+            assert (got[o:o + n] == want[p % 4]).all(), p
+    finally:
+        ctx.close()
+
+
 def test_runs_that_pass_over_tiles(scout, oracle):
     """Bit-packed runs of up to 40 000 groups (headers of three bytes, payloads that span hundreds of tiles)
     between short runs, RLE runs of up to 2^22 values (headers of up to four bytes), at several widths."""

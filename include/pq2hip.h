@@ -461,8 +461,20 @@ uint64_t pq2_zigzag_leb128_encode(int64_t value, uint8_t container[10]);
  * callers (README.md:107-128: one thread per column chunk). */
 int32_t pq2_partition_pages(const pq2_page_desc *descs, uint64_t n_pages, uint32_t n_parts, uint64_t *bounds);
 
+/* The same split over costs the caller supplies (one per page, any unit), and
+ * the costs this library would supply where the streams lie in host memory
+ * (`h_in`; NULL: bytes only, what pq2_partition_pages uses): the bytes a page
+ * moves plus 256 for every run header it is estimated to hold, from a walk
+ * over its first 256 headers (src/encoding/hybrid_rle/decoder.rs:30-64) -- a
+ * page of runs of a few values costs a GPU ten times what its bytes say.  No
+ * counterpart in the reference, which leaves the split to its callers
+ * (README.md:107-128). */
+int32_t pq2_partition_by_cost(const uint64_t *costs, uint64_t n_pages, uint32_t n_parts, uint64_t *bounds);
+int32_t pq2_page_costs(const void *h_in, uint64_t in_bytes, const pq2_page_desc *descs, uint64_t n_pages,
+                       uint64_t *costs);
+
 /* One process, several GPUs: the batch of pq2_decode_batch_host split with
- * pq2_partition_pages over `n_ctx` contexts (one per GPU, from
+ * pq2_page_costs / pq2_partition_by_cost over `n_ctx` contexts (one per GPU, from
  * pq2_ctx_create(device)), each driven by a host thread of its own; no data
  * moves between the GPUs.  This is the reference's thread-per-column-chunk
  * recipe (README.md:107-128) with GPUs in place of threads.  Page outputs

@@ -112,6 +112,8 @@ SIGNATURES = {
     "pq2_zigzag_leb128_decode": (C.c_int32, [C.c_void_p, C.c_uint64, C.POINTER(C.c_int64), u64p]),
     "pq2_zigzag_leb128_encode": (C.c_uint64, [C.c_int64, u8p]),
     "pq2_partition_pages": (C.c_int32, [C.c_void_p, C.c_uint64, C.c_uint32, u64p]),
+    "pq2_partition_by_cost": (C.c_int32, [u64p, C.c_uint64, C.c_uint32, u64p]),
+    "pq2_page_costs": (C.c_int32, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, u64p]),
     "pq2_multi_decode": (C.c_int32, [C.POINTER(C.c_void_p), C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
                                      C.c_void_p, C.c_uint64, C.c_void_p]),
     "pq2_ceil8": (C.c_uint64, [C.c_uint64]),
@@ -442,17 +444,31 @@ def multi_decode(contexts, data, descs, out_values=None, out=None):
     return out, status
 
 
-def page_costs(descs):
-    """What pq2_partition_pages balances: the bytes a page moves through HBM."""
+def page_costs(descs, data=None):
+    """What the page split balances (pq2_page_costs): the bytes a page moves through HBM and, where the streams are
+    at hand (`data`: the input buffer in host memory), 256 for every run header the page is estimated to hold."""
     descs = np.ascontiguousarray(descs, dtype=PAGE_DESC_DTYPE)
-    return descs["in_len"].astype(np.int64) + 4 * descs["num_values"].astype(np.int64)
+    costs = np.zeros(len(descs), dtype=np.uint64)
+    if data is not None:
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+    st = lib().pq2_page_costs(ptr(data) if data is not None else None, data.size if data is not None else 0,
+                              ptr(descs), len(descs), costs.ctypes.data_as(u64p))
+    if st != OK:
+        raise_for_status(st, "pq2_page_costs")
+    return costs.astype(np.int64)
 
 
-def partition_pages(descs, n_parts):
-    """Contiguous page ranges balanced on page cost (stream bytes + value bytes): returns n_parts + 1 bounds."""
+def partition_pages(descs, n_parts, data=None):
+    """Contiguous page ranges balanced on page cost: returns n_parts + 1 bounds.  Without `data` the cost is stream
+    bytes + value bytes (pq2_partition_pages); with the input buffer, run headers count too (pq2_page_costs,
+    pq2_partition_by_cost: what pq2_multi_decode does)."""
     descs = np.ascontiguousarray(descs, dtype=PAGE_DESC_DTYPE)
     bounds = np.zeros(n_parts + 1, dtype=np.uint64)
-    st = lib().pq2_partition_pages(ptr(descs), len(descs), n_parts, bounds.ctypes.data_as(u64p))
+    if data is None:
+        st = lib().pq2_partition_pages(ptr(descs), len(descs), n_parts, bounds.ctypes.data_as(u64p))
+    else:
+        costs = page_costs(descs, data).astype(np.uint64)
+        st = lib().pq2_partition_by_cost(costs.ctypes.data_as(u64p), len(descs), n_parts, bounds.ctypes.data_as(u64p))
     if st != OK:
         raise_for_status(st, "pq2_partition_pages")
     return bounds.astype(np.int64)

@@ -1873,13 +1873,70 @@ int32_t pq2_delta_bitpacked_decode_host(pq2_ctx *ctx, const void *values, uint64
 // What a page costs its GPU: the bytes it moves through HBM, stream in and values out.
 static inline uint64_t page_cost(const pq2_page_desc &d) { return uint64_t(d.in_len) + d.num_values * sizeof(uint32_t); }
 
+// A run header costs a decoder about what 256 bytes of traffic cost it (BASELINE's adversarial pages, a header per
+// six values, take a GPU 7 to 13 times as long as index pages of the same size: 9 to 16 us a page against 1.2).
+static constexpr uint64_t kHeaderCostBytes = 256;
+// How many run headers a stream holds, from its first headers (uleb128.rs:3-23, decoder.rs:30-64): exact where the
+// sample reaches the stream's end, else the sample's bytes per header carried over the whole stream.
+static uint64_t estimate_headers(const uint8_t *stream, uint64_t len, uint32_t num_bits) {
+    if (len == 0 || num_bits == 0 || num_bits > 32) return 0;
+    const uint64_t rle_bytes = (num_bits + 7) / 8;
+    uint64_t pos = 0, headers = 0;
+    while (pos < len && headers < 256) {
+        uint64_t indicator = 0;
+        uint32_t shift = 0;
+        bool ended = false;
+        while (pos < len && shift < 64) {
+            const uint8_t byte = stream[pos++];
+            indicator |= uint64_t(byte & 0x7f) << shift;
+            shift += 7;
+            if (!(byte & 0x80)) {
+                ended = true;
+                break;
+            }
+        }
+        if (!ended) break;
+        ++headers;
+        const uint64_t body = (indicator & 1) ? (indicator >> 1) * num_bits : rle_bytes;
+        if (body > len - pos) {
+            pos = len;
+            break;
+        }
+        pos += body;
+    }
+    if (headers == 0) return 0;
+    if (pos >= len) return headers;
+    return static_cast<uint64_t>(double(headers) * double(len) / double(pos) + 0.5);
+}
+
+int32_t pq2_page_costs(const void *h_in, uint64_t in_bytes, const pq2_page_desc *descs, uint64_t n_pages, uint64_t *costs) {
+    if (n_pages && (!descs || !costs)) return PQ2_INVALID_PARAMETER;
+    for (uint64_t i = 0; i < n_pages; ++i) {
+        const pq2_page_desc &d = descs[i];
+        costs[i] = page_cost(d);
+        if (!h_in) continue;
+        if (d.in_off > in_bytes || d.in_len > in_bytes - d.in_off) return PQ2_INVALID_PARAMETER;
+        if (d.num_values == 0) continue;
+        const uint64_t headers = estimate_headers(static_cast<const uint8_t *>(h_in) + d.in_off, d.in_len, d.num_bits);
+        costs[i] += std::min<uint64_t>(headers, d.num_values) * kHeaderCostBytes;  // (a run that counts holds a value)
+    }
+    return PQ2_OK;
+}
+
 int32_t pq2_partition_pages(const pq2_page_desc *descs, uint64_t n_pages, uint32_t n_parts, uint64_t *bounds) {
     if (n_parts == 0 || !bounds || (n_pages && !descs)) return PQ2_INVALID_PARAMETER;
+    std::vector<uint64_t> costs(n_pages);
+    for (uint64_t i = 0; i < n_pages; ++i) costs[i] = page_cost(descs[i]);
+    return pq2_partition_by_cost(costs.data(), n_pages, n_parts, bounds);
+}
+
+int32_t pq2_partition_by_cost(const uint64_t *costs, uint64_t n_pages, uint32_t n_parts, uint64_t *bounds) {
+    if (n_parts == 0 || !bounds || (n_pages && !costs)) return PQ2_INVALID_PARAMETER;
     unsigned __int128 total = 0;
     uint64_t largest = 0;
     for (uint64_t i = 0; i < n_pages; ++i) {
-        total += page_cost(descs[i]);
-        largest = std::max(largest, page_cost(descs[i]));
+        total += costs[i];
+        largest = std::max(largest, costs[i]);
     }
     // first cut: page i goes to the part in which the midpoint of its cost range falls
     std::vector<uint64_t> even(n_parts + 1, 0);
@@ -1888,8 +1945,8 @@ int32_t pq2_partition_pages(const pq2_page_desc *descs, uint64_t n_pages, uint32
         unsigned __int128 before = 0;
         for (uint32_t r = 1; r <= n_parts; ++r) {
             const unsigned __int128 target2 = total * 2 * r / n_parts;  // twice the cumulative target
-            while (page < n_pages && before * 2 + page_cost(descs[page]) <= target2) {
-                before += page_cost(descs[page]);
+            while (page < n_pages && before * 2 + costs[page] <= target2) {
+                before += costs[page];
                 ++page;
             }
             even[r] = (r == n_parts) ? n_pages : page;
@@ -1899,7 +1956,7 @@ int32_t pq2_partition_pages(const pq2_page_desc *descs, uint64_t n_pages, uint32
         unsigned __int128 worst = 0;
         for (uint32_t r = 0; r < n_parts; ++r) {
             unsigned __int128 c = 0;
-            for (uint64_t i = b[r]; i < b[r + 1]; ++i) c += page_cost(descs[i]);
+            for (uint64_t i = b[r]; i < b[r + 1]; ++i) c += costs[i];
             worst = std::max(worst, c);
         }
         return worst;
@@ -1910,7 +1967,7 @@ int32_t pq2_partition_pages(const pq2_page_desc *descs, uint64_t n_pages, uint32
         uint32_t part = 1;
         unsigned __int128 c = 0;
         for (uint64_t i = 0; i < n_pages; ++i) {
-            const uint64_t w = page_cost(descs[i]);
+            const uint64_t w = costs[i];
             if (c + w > limit && c > 0) {
                 if (part == n_parts) return false;
                 if (b) (*b)[part] = i;
@@ -1952,8 +2009,10 @@ int32_t pq2_multi_decode(pq2_ctx *const *ctxs, uint32_t n_ctx, const void *h_in,
         if (d.out_off > out_values || d.num_values > out_values - d.out_off)
             return fail(ctxs[0], PQ2_INVALID_PARAMETER, "page output outside the output buffer");
     }
-    std::vector<uint64_t> bounds(n_ctx + 1, 0);
-    int32_t st = pq2_partition_pages(descs, n_pages, n_ctx, bounds.data());
+    // (the streams are at hand: the parts are balanced on bytes and run headers, pq2_page_costs)
+    std::vector<uint64_t> bounds(n_ctx + 1, 0), costs(n_pages);
+    int32_t st = pq2_page_costs(h_in, in_bytes, descs, n_pages, costs.data());
+    if (st == PQ2_OK) st = pq2_partition_by_cost(costs.data(), n_pages, n_ctx, bounds.data());
     if (st != PQ2_OK) return st;
     struct Span { uint64_t in_lo, in_hi, out_lo, out_hi; };
     std::vector<Span> spans(n_ctx, Span{in_bytes, 0, out_values, 0});

@@ -47,6 +47,18 @@ impl Context {
         unsafe { sys::pq2_partition_pages(descs.as_ptr(), descs.len() as u64, n_parts, bounds.as_mut_ptr()) };
         bounds
     }
+    /// `pq2_page_costs` + `pq2_partition_by_cost`: the same with the streams at hand (`input`, host memory), balanced
+    /// on bytes and on the run headers the pages are estimated to hold.
+    pub fn partition_pages_of(input: &[u8], descs: &[sys::pq2_page_desc], n_parts: u32) -> Vec<u64> {
+        let mut costs = vec![0u64; descs.len()];
+        let mut bounds = vec![0u64; n_parts as usize + 1];
+        unsafe {
+            sys::pq2_page_costs(input.as_ptr() as *const _, input.len() as u64, descs.as_ptr(), descs.len() as u64,
+                                costs.as_mut_ptr());
+            sys::pq2_partition_by_cost(costs.as_ptr(), descs.len() as u64, n_parts, bounds.as_mut_ptr());
+        }
+        bounds
+    }
 }
 impl Drop for Context {
     fn drop(&mut self) {

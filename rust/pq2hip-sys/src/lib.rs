@@ -152,6 +152,9 @@ extern "C" {
     pub fn pq2_zigzag_leb128_encode(value: i64, container: *mut u8) -> u64;
     // ---- several GPUs ----
     pub fn pq2_partition_pages(descs: *const pq2_page_desc, n_pages: u64, n_parts: u32, bounds: *mut u64) -> i32;
+    pub fn pq2_partition_by_cost(costs: *const u64, n_pages: u64, n_parts: u32, bounds: *mut u64) -> i32;
+    pub fn pq2_page_costs(h_in: *const c_void, in_bytes: u64, descs: *const pq2_page_desc, n_pages: u64,
+                          costs: *mut u64) -> i32;
     pub fn pq2_multi_decode(ctxs: *const *mut pq2_ctx, n_ctx: u32, h_in: *const c_void, in_bytes: u64,
                             descs: *const pq2_page_desc, n_pages: u64, h_out: *mut u32, out_values: u64,
                             status: *mut i32) -> i32;

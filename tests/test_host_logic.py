@@ -238,6 +238,45 @@ def test_partition_pages_balances_cost():
         assert got == best, (trial, m, parts, got, best)
 
 
+def test_page_costs_see_run_headers(oracle):
+    """With the streams at hand a page is priced on its bytes and on the run headers it holds (256 a header,
+    estimated from the first 256): pages of runs of a few values, which cost a GPU many times what their bytes say,
+    get fewer to a part than index pages of long runs; the estimate is near the run iterator's count; streams that are empty, cut or junk have a price all the same."""
+    from parquet2_amd import page_costs, synth
+    from parquet2_amd.encoding import hybrid_rle
+
+    n = 50000
+    long_runs = [synth.dict_page(synth.seed_for(2, p), n, 12)[0] for p in range(12)]
+    short_runs = [synth.adversarial(synth.seed_for(4, p), n, 12)[0] for p in range(12)]
+    batch = synth.PageBatch()
+    for s in long_runs + short_runs:
+        batch.add(s, 12, n)
+    data, descs, _ = batch.finish()
+    plain, seen = page_costs(descs), page_costs(descs, data)
+    assert (plain == descs["in_len"].astype(np.int64) + 4 * n).all()
+    for i, s in enumerate(long_runs + short_runs):
+        headers = sum(1 for _ in hybrid_rle.Decoder(bytes(s), 12))
+        estimate = (seen[i] - plain[i]) / 256
+        # (a sample of 256 headers: close where the stream is the same all along, a rough figure where it is not)
+        assert abs(estimate - headers) <= (0.3 if i < 12 else 0.05) * headers + 2, (i, estimate, headers)
+    assert seen[12:].min() > 5 * seen[:12].max()
+    by_bytes, by_headers = partition_pages(descs, 2), partition_pages(descs, 2, data)
+    assert 6 <= by_bytes[1] <= 14                      # about half of the pages either side
+    assert by_headers[1] >= 16                         # all the long-run pages and a few of the others weigh as much as the rest
+    loads = [int(seen[by_headers[i]:by_headers[i + 1]].sum()) for i in range(2)]
+    assert abs(loads[0] - loads[1]) <= int(seen.max())
+    # whatever the bytes are, there is a price and it is at least the bytes'
+    rng = np.random.default_rng(5)
+    odd = [np.zeros(0, np.uint8), np.frombuffer(b"\x80" * 12, np.uint8), rng.integers(0, 256, 3000, dtype=np.uint8),
+           long_runs[0][:7], short_runs[0][:1]]
+    batch = synth.PageBatch()
+    for k, s in enumerate(odd):
+        batch.add(s, [12, 12, 7, 12, 40][k], 100)
+    data, descs, _ = batch.finish()
+    seen = page_costs(descs, data)
+    assert (seen >= page_costs(descs)).all() and (seen <= page_costs(descs) + 256 * 100).all()
+
+
 def test_delta_bitpacked_encode_and_zigzag(kats, oracle):
     """The host-side write path of DELTA_BINARY_PACKED against the reference's byte vectors
     (src/encoding/delta_bitpacked/encoder.rs:84-124, zigzag_leb128.rs:23-64) and, byte for byte, the oracle."""

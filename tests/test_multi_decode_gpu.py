@@ -93,12 +93,12 @@ def test_the_same_context_twice_is_refused(contexts):
 
 
 def test_every_context_decodes_its_part_of_the_partition(contexts):
-    """The page ranges the contexts get are pq2_partition_pages's."""
+    """The page ranges the contexts get are those of pq2_page_costs + pq2_partition_by_cost over the host's streams."""
     from parquet2_amd._lib import lib
 
     (data, descs, out_values), _ = mixed_batch(150, 17, True)
     k = min(3, len(contexts))
-    bounds = partition_pages(descs, k)
+    bounds = partition_pages(descs, k, data)
     before = [lib().pq2_ctx_pages_total(c._h) for c in contexts[:k]]
     multi_decode(contexts[:k], data, descs, out_values)
     after = [lib().pq2_ctx_pages_total(c._h) for c in contexts[:k]]

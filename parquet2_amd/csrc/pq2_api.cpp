@@ -407,7 +407,8 @@ bool auto_takes_scout(const pq2_page_desc *descs, uint64_t n_pages) {
 int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const pq2_page_desc *descs, uint64_t n_pages,
                       uint32_t *d_out, uint64_t out_values, hipStream_t stream, const FrontJob *front = nullptr,
                       uint32_t min_max_bits = 0, const TileMask *mask = nullptr, const FusedDict *fused = nullptr,
-                      const BitmapOut *bits = nullptr, const ExpandLookup *lookup = nullptr) {
+                      const BitmapOut *bits = nullptr, const ExpandLookup *lookup = nullptr,
+                      hipEvent_t before_kernels = nullptr) {
     ctx->expand_looked_up = false;
     if (n_pages > 0x7fffffffull) return fail(ctx, PQ2_INVALID_PARAMETER, "too many pages in one batch");
     if (n_pages > 0 && !descs) return fail(ctx, PQ2_INVALID_PARAMETER, "descs is NULL");
@@ -647,6 +648,20 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
     // leaves its verdict in device memory; the ring_kernel launch goes out behind it at once and returns
     // immediately if the verdict is "no", so that the usual case costs the few microseconds of the probe and no idle
     // time; the host reads the verdict when the probe has run and, on a "no", enqueues the scout kernels instead.
+    if (per_page) {
+        if (!ctx->d_tickets.ptr) {
+            const size_t ticket_bytes = pq2_cu_ticket_bytes() + pq2_ring_ticket_bytes();
+            if ((st = reserve(ctx, ctx->d_tickets, ticket_bytes))) return st;
+            PQ2_HIP(ctx, hipMemsetAsync(ctx->d_tickets.ptr, 0, ticket_bytes, stream));
+        }
+        if (fused)  // the walking wave and the expanding waves merge what they report: from 0
+            PQ2_HIP(ctx, hipMemsetAsync(d_status, 0, n_pages * sizeof(int32_t), stream));
+        if (bits)  // the expanding waves add up a page's set bits
+            PQ2_HIP(ctx, hipMemsetAsync(bits->d_meta, 0, n_pages * 2 * sizeof(uint32_t), stream));
+    }
+    // what the kernels read besides the descriptors (the streams, records of the caller's) is ready behind this
+    // event: the uploads and fills above do not wait for it
+    if (before_kernels) PQ2_HIP(ctx, hipStreamWaitEvent(stream, before_kernels, 0));
     uint32_t *d_go = nullptr;
     ctx->last_density_headers = 0;
     // (with the dictionary lookup inside ring_kernel as well: on a "no" the caller takes the indices through memory)
@@ -684,15 +699,6 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
         PQ2_HIP(ctx, hipEventRecord(ctx->density_done, stream));
     }
     if (per_page) {
-        if (!ctx->d_tickets.ptr) {
-            const size_t ticket_bytes = pq2_cu_ticket_bytes() + pq2_ring_ticket_bytes();
-            if ((st = reserve(ctx, ctx->d_tickets, ticket_bytes))) return st;
-            PQ2_HIP(ctx, hipMemsetAsync(ctx->d_tickets.ptr, 0, ticket_bytes, stream));
-        }
-        if (fused)  // the walking wave and the expanding waves merge what they report: from 0
-            PQ2_HIP(ctx, hipMemsetAsync(d_status, 0, n_pages * sizeof(int32_t), stream));
-        if (bits)  // the expanding waves add up a page's set bits
-            PQ2_HIP(ctx, hipMemsetAsync(bits->d_meta, 0, n_pages * 2 * sizeof(uint32_t), stream));
         if ((st = stamped(true, stream, [&] {
                  uint32_t *const ring_tickets = static_cast<uint32_t *>(ctx->d_tickets.ptr) + pq2_cu_ticket_bytes() / 4u;
                  if (fused)
@@ -729,7 +735,7 @@ int32_t enqueue_batch(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const p
             const uint32_t expected = ctx->last_density_headers;
             ctx->mode = pq2_ctx::kScout;
             st = enqueue_batch(ctx, d_in, in_bytes, descs, n_pages, d_out, out_values, stream, front, min_max_bits, mask,
-                               fused, bits, lookup);
+                               fused, bits, lookup, nullptr /* (waited for above already) */);
             ctx->mode = was;
             ctx->last_density_headers = expected;
             return st;
@@ -966,19 +972,19 @@ int32_t pq2_decode_batch_device(pq2_ctx *ctx, const void *d_in, uint64_t in_byte
     return PQ2_OK;
 }
 
-int32_t pq2_decode_validity_bitmap_batch_device(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes,
-                                                const pq2_page_desc *descs, uint64_t n_pages, void *d_bitmap,
-                                                uint64_t bitmap_bytes, uint32_t *rows, uint32_t *set_counts,
-                                                int32_t *status, void *stream_) {
+// pq2_decode_validity_bitmap_batch_device; `before_kernels` (may be null): an event the kernels wait for on `stream`,
+// but not the upload of the descriptors.
+static int32_t validity_bitmaps(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const pq2_page_desc *descs,
+                                uint64_t n_pages, void *d_bitmap, uint64_t bitmap_bytes, uint32_t *rows,
+                                uint32_t *set_counts, int32_t *status, hipStream_t stream, hipEvent_t before_kernels) {
     if (!ctx) return PQ2_INVALID_PARAMETER;
     PQ2_HIP(ctx, hipSetDevice(ctx->device));
     if (n_pages > 0x7fffffffull) return fail(ctx, PQ2_INVALID_PARAMETER, "too many pages in one batch");
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
     int32_t st = reserve(ctx, ctx->d_bit_meta, std::max<uint64_t>(n_pages, 1) * 2 * sizeof(uint32_t));
     if (st != PQ2_OK) return st;
     const BitmapOut bits{bitmap_bytes, static_cast<uint32_t *>(ctx->d_bit_meta.ptr)};
     st = enqueue_batch(ctx, d_in, in_bytes, descs, n_pages, static_cast<uint32_t *>(d_bitmap), 0, stream, nullptr, 0,
-                       nullptr, nullptr, &bits);
+                       nullptr, nullptr, &bits, nullptr, before_kernels);
     if (st != PQ2_OK) return st;
     if ((rows || set_counts) && n_pages) {
         std::vector<uint32_t> meta(n_pages * 2);
@@ -992,6 +998,14 @@ int32_t pq2_decode_validity_bitmap_batch_device(pq2_ctx *ctx, const void *d_in, 
     }
     if (status) return fetch_status(ctx, status, n_pages);
     return PQ2_OK;
+}
+
+int32_t pq2_decode_validity_bitmap_batch_device(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes,
+                                                const pq2_page_desc *descs, uint64_t n_pages, void *d_bitmap,
+                                                uint64_t bitmap_bytes, uint32_t *rows, uint32_t *set_counts,
+                                                int32_t *status, void *stream) {
+    return validity_bitmaps(ctx, d_in, in_bytes, descs, n_pages, d_bitmap, bitmap_bytes, rows, set_counts, status,
+                            static_cast<hipStream_t>(stream), nullptr);
 }
 
 int32_t pq2_decode_dict_batch_device(pq2_ctx *ctx, const void *d_in, uint64_t in_bytes, const pq2_page_desc *descs,
@@ -1182,11 +1196,13 @@ int32_t pq2_decode_optional_dict_batch_device(pq2_ctx *ctx, const void *d_in, ui
                 dir_words += idx_descs[i].num_values / step + 3;  // (a tile's first span asks for three entries)
             }
             if ((st = reserve(ctx, ctx->d_rowdir, dir_words * sizeof(uint32_t)))) return st;
+            // The level streams on the child's stream, behind whatever the caller's stream held at the call -- the
+            // kernels, that is: the uploads of descriptors and the fills go ahead of that (here and for the index
+            // streams below), so that they run beside the kernel before them instead of between two kernels.
             PQ2_HIP(ctx, hipEventRecord(ctx->bits_fork, stream));
-            PQ2_HIP(ctx, hipStreamWaitEvent(lane->lane_stream, ctx->bits_fork, 0));
-            st = pq2_decode_validity_bitmap_batch_device(lane, d_in, in_bytes, levels.data(), n_pages, lane->d_out.ptr,
-                                                         std::max<uint64_t>(bitmap_bytes, 4), nullptr, nullptr, nullptr,
-                                                         lane->lane_stream);
+            st = validity_bitmaps(lane, d_in, in_bytes, levels.data(), n_pages, lane->d_out.ptr,
+                                  std::max<uint64_t>(bitmap_bytes, 4), nullptr, nullptr, nullptr, lane->lane_stream,
+                                  ctx->bits_fork);
             if (st != PQ2_OK) return fail(ctx, st, pq2_last_error(lane));
             // one block: the GatherPage records ring_kernel takes the dictionaries from, then the RingNullable records
             const size_t dict_recs = n_pages * sizeof(GatherPage);
@@ -1211,16 +1227,18 @@ int32_t pq2_decode_optional_dict_batch_device(pq2_ctx *ctx, const void *d_in, ui
                 nl[i].rows = skip ? 0u : static_cast<uint32_t>(def_descs[i].num_values);
                 nl[i].idx_values = static_cast<uint32_t>(indices[i].num_values);
             }
-            if ((st = upload_block(ctx, bytes, lane->lane_stream))) return st;
+            // (the records go up on the caller's stream, beside the bitmaps' kernel; rowdir_kernel waits for them)
+            if ((st = upload_block(ctx, bytes, stream))) return st;
+            PQ2_HIP(ctx, hipStreamWaitEvent(lane->lane_stream, ctx->gather_copied, 0));
             const uint8_t *const d_nulls = static_cast<const uint8_t *>(ctx->d_gather.ptr) + dict_recs;
             PQ2_HIP(ctx, pq2_launch_rowdir(d_nulls, static_cast<uint32_t>(n_pages), lane->lane_stream));
             PQ2_HIP(ctx, hipEventRecord(ctx->bits_joined, lane->lane_stream));
-            PQ2_HIP(ctx, hipStreamWaitEvent(stream, ctx->bits_joined, 0));
             FusedDict fd{ctx->d_gather.ptr, value_size / 4, static_cast<uint32_t>(dict_max_bytes)};
             fd.d_nulls = d_nulls;
             // (the descriptors' output offsets only have to be consistent: the kernel writes through the records above)
             if ((st = enqueue_batch(ctx, d_in, in_bytes, indices.data(), n_pages, static_cast<uint32_t *>(d_out),
-                                    std::max<uint64_t>(idx_values, 1), stream, nullptr, 0, nullptr, &fd)))
+                                    std::max<uint64_t>(idx_values, 1), stream, nullptr, 0, nullptr, &fd, nullptr, nullptr,
+                                    ctx->bits_joined)))
                 return st;
             PQ2_HIP(ctx, pq2_launch_nullable_status(static_cast<int32_t *>(ctx->d_status.ptr),
                                                     static_cast<const int32_t *>(lane->d_status.ptr),

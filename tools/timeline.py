@@ -1,18 +1,14 @@
-#!/usr/bin/env python3
-"""Prints the start/end (us, relative) of the pq2 kernels of the last batch from a rocprofv3 kernel-trace CSV."""
+"""Prints the last steps of a rocprofv3 --kernel-trace csv as a timeline: start relative to the first listed kernel,
+duration and the idle time in front of every kernel (us).  python tools/timeline.py <kernel_trace.csv> [kernels = 12]"""
 import csv
-import glob
 import sys
 
-rows = []
-for path in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
-    for r in csv.DictReader(open(path)):
-        if "pq2" in r["Kernel_Name"]:
-            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].split("::")[-1],
-                         r.get("Stream_Id", "?"), r.get("Queue_Id", "?")))
-rows.sort()
-n = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-rows = rows[-n:]
-t0 = rows[0][0]
-for s, e, k, st, q in rows:
-    print("%-16s start %9.1f  end %9.1f  dur %8.1f us  stream %s queue %s" % (k, (s - t0) / 1e3, (e - t0) / 1e3, (e - s) / 1e3, st, q))
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+rows = rows[-int(sys.argv[2]) if len(sys.argv) > 2 else -12:]
+t0 = int(rows[0]["Start_Timestamp"])
+busy_until = t0
+for r in rows:
+    a, b = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    print(f"{(a - t0) / 1e3:9.1f} us  +{(b - a) / 1e3:8.1f}  idle before {max(0, a - busy_until) / 1e3:7.1f}  q{r.get('Queue_Id', '?')}  {r['Kernel_Name'][:70]}")
+    busy_until = max(busy_until, b)

@@ -1257,13 +1257,11 @@ int32_t pq2_decode_optional_dict_batch_device(pq2_ctx *ctx, const void *d_in, ui
         PQ2_HIP(ctx, hipEventRecord(ctx->bits_fork, stream));
         uint32_t *d_idx = static_cast<uint32_t *>(ctx->d_indices.ptr);
         if ((st = enqueue_batch(ctx, d_in, in_bytes, indices.data(), n_pages, d_idx, idx_values, stream))) return st;
-        PQ2_HIP(ctx, hipStreamWaitEvent(lane->lane_stream, ctx->bits_fork, 0));
-        st = pq2_decode_validity_bitmap_batch_device(lane, d_in, in_bytes, levels.data(), n_pages, lane->d_out.ptr,
-                                                     std::max<uint64_t>(bitmap_bytes, 4), nullptr, nullptr, nullptr,
-                                                     lane->lane_stream);
+        st = validity_bitmaps(lane, d_in, in_bytes, levels.data(), n_pages, lane->d_out.ptr,
+                              std::max<uint64_t>(bitmap_bytes, 4), nullptr, nullptr, nullptr, lane->lane_stream,
+                              ctx->bits_fork);
         if (st != PQ2_OK) return fail(ctx, st, pq2_last_error(lane));
         PQ2_HIP(ctx, hipEventRecord(ctx->bits_joined, lane->lane_stream));
-        PQ2_HIP(ctx, hipStreamWaitEvent(stream, ctx->bits_joined, 0));
         const size_t bytes = n_pages * sizeof(OptionalPage);
         if ((st = stage_block(ctx, bytes, bytes))) return st;
         OptionalPage *g = static_cast<OptionalPage *>(ctx->h_gather);
@@ -1286,6 +1284,7 @@ int32_t pq2_decode_optional_dict_batch_device(pq2_ctx *ctx, const void *d_in, ui
             if (lane->host_status[i] != PQ2_OK) ctx->host_status[i] = lane->host_status[i];
         }
         if ((st = upload_block(ctx, bytes, stream))) return st;
+        PQ2_HIP(ctx, hipStreamWaitEvent(stream, ctx->bits_joined, 0));  // (behind the upload: that one need not wait)
         PQ2_HIP(ctx, pq2_launch_optional_bits(ctx->d_gather.ptr, static_cast<uint32_t>(n_pages), value_size / 4,
                                               static_cast<int32_t *>(ctx->d_status.ptr),
                                               static_cast<const int32_t *>(lane->d_status.ptr), largest_dict, stream));

@@ -628,15 +628,20 @@ __global__ __launch_bounds__(256) void scout_count_kernel(const PageDev *__restr
         wave_sync();
         uint32_t x = pos - t0, mine = kScoutSeg;  // mine: the offset at which the chain enters this lane's segment
         uint32_t stop = kScoutSeg;                // ... and the offset of its segment from which the lane keeps out
-        while (x < kScoutTile) {
-            if (lane == (x >> 5)) mine = x & 31u;
-            const uint32_t v = __builtin_amdgcn_readfirstlane((uint32_t)tbl[table_slot(x)]);
-            if (v & kScoutEsc) {
-                x = v & 0x7fffu;  // in the same segment, at or behind the entry
-                if (lane == (x >> 5)) stop = x & 31u;
-                break;
+        // (one exit from the loop, one comparison a step -- an entry that leaves the tile and an escape are both at
+        // least kScoutTile --: the scalar unit, which all waves of a compute unit share, sets this kernel's pace)
+        static_assert(kScoutEsc >= kScoutTile, "an escape compares as an exit");
+        if (x < kScoutTile) {
+            for (;;) {
+                const uint32_t seg = x >> 5, off = x & 31u;
+                mine = lane == seg ? off : mine;
+                x = __builtin_amdgcn_readfirstlane((uint32_t)tbl[off * kScoutRow + seg]);
+                if (x >= kScoutTile) break;
             }
-            x = v;
+            if (x & kScoutEsc) {
+                x &= 0x7fffu;  // in the same segment, at or behind the entry
+                stop = lane == (x >> 5) ? (x & 31u) : stop;
+            }
         }
         // from header to header through the lane's 32 bytes (all of them headers of one or two bytes whose runs lie
         // inside the stream: the table step has seen to that up to `stop`), as many steps as the segment with the

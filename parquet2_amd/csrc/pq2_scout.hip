@@ -781,6 +781,7 @@ __global__ __launch_bounds__(kScoutScanThreads) void scout_scan_kernel(const Pag
     if (page >= n_pages) return;
     const PageDev pg = pages[page];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t wave_id = __builtin_amdgcn_readfirstlane(wave);
     const uint32_t n = pg.num_values;
     if (n == 0u) {
         if (tid == 0) status[page] = 0;
@@ -810,10 +811,14 @@ __global__ __launch_bounds__(kScoutScanThreads) void scout_scan_kernel(const Pag
         const uint32_t ir = wave_inclusive_sum(r);
         if (lane == 63u) wave_vals[wave] = iv, wave_runs[wave] = ir;
         __syncthreads();
-        uint32_t bv = carry_vals, br = carry_runs;
-        for (uint32_t i = 0; i < kWaves; ++i) {
-            if (i < wave) bv = min(bv + wave_vals[i], kValueCap), br += wave_runs[i];
-        }
+        // the waves' totals, summed up by every wave for itself: lane i holds wave i's, one prefix sum over the
+        // lanes gives the sum of the waves before this one and the sum of all (a chain of 2 x 16 LDS reads before)
+        static_assert(kWaves <= 64u, "a lane for every wave");
+        const uint32_t tv = wave_inclusive_sum_saturating(lane < kWaves ? wave_vals[lane] : 0u, kValueCap);
+        const uint32_t tr = wave_inclusive_sum(lane < kWaves ? wave_runs[lane] : 0u);
+        const uint32_t before = (wave_id + 63u) & 63u;  // (wave 0: lane 63, not used)
+        const uint32_t bv = min(carry_vals + (wave_id != 0u ? (uint32_t)__builtin_amdgcn_readlane(tv, before) : 0u), kValueCap);
+        const uint32_t br = carry_runs + (wave_id != 0u ? (uint32_t)__builtin_amdgcn_readlane(tr, before) : 0u);
         const uint32_t excl_v = min(bv + (uint32_t)__builtin_amdgcn_update_dpp(0u, iv, 0x138, 0xf, 0xf, false), kValueCap);  // wave_shr:1
         const uint32_t incl_v = min(bv + iv, kValueCap);
         if (in) {
@@ -825,7 +830,8 @@ __global__ __launch_bounds__(kScoutScanThreads) void scout_scan_kernel(const Pag
             if (incl_v >= n && excl_v < n) atomicMin(&first_full, k);
             if (rf & (kScoutPanic | kScoutBad)) atomicOr(&any_flags, rf & (kScoutPanic | kScoutBad));
         }
-        for (uint32_t i = 0; i < kWaves; ++i) carry_vals = min(carry_vals + wave_vals[i], kValueCap), carry_runs += wave_runs[i];
+        carry_vals = min(carry_vals + (uint32_t)__builtin_amdgcn_readlane(tv, kWaves - 1u), kValueCap);
+        carry_runs += (uint32_t)__builtin_amdgcn_readlane(tr, kWaves - 1u);
     }
     __syncthreads();
     if (tid == 0) {
